@@ -1,0 +1,160 @@
+"""Pin the CPU oracle (oracle/mvt_oracle.py) against golden vectors produced by the reference.
+
+The .npz files were written by tests/golden/make_golden.py, which imports the reference from
+/root/reference in the build container.  These tests need neither the reference nor a GPU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from mvtracker_amd import synth
+from oracle import mvt_oracle as O
+
+CFG = O.TrackerConfig()
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def W():
+    return O.make_weights(CFG, seed=0)
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_state_dict_contract(golden):
+    g = golden("state_dict_shapes")
+    shapes = O.state_dict_shapes(CFG)
+    assert sorted(shapes) == list(g["keys"])
+    assert [str(tuple(shapes[k])) for k in sorted(shapes)] == list(g["shapes"])
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(g["n_params"]) == 22607356
+    assert CFG.token_dim == int(g["token_dim"]) == 581
+
+
+def test_weights_recipe_matches_synth(W):
+    sd = synth.make_state_dict(O.state_dict_shapes(CFG), seed=0)
+    for k, v in W.items():
+        assert np.array_equal(v.numpy(), sd[k]), k
+
+
+def test_encoder(golden, W):
+    g = golden("encoder_64x96")
+    close(O.encoder(W, T(g["img"])), g["out"], rtol=1e-4, atol=1e-5)
+
+
+def test_pyramid(golden):
+    g = golden("pyramid_small")
+    for lvl in range(3):
+        xyz, fvec, valid = O.pointcloud_level(T(g["fmaps"]), T(g["depths_strided"]), T(g["intrs"]), T(g["extrs"]), 4, lvl,
+                                              return_valid=True)
+        close(xyz, g[f"xyz{lvl}"])
+        assert np.array_equal(fvec.numpy(), g[f"fvec{lvl}"])
+        assert np.array_equal(valid.numpy(), g[f"valid{lvl}"])
+
+
+@pytest.mark.parametrize("mode", ["cdist", "exact"])
+def test_corr_sample(golden, mode):
+    g = golden("corr_sample_small")
+    out, idx = O.corr_sample(T(g["xyz"]), T(g["fvec"]), T(g["targets"]), T(g["coords"]), 16, 1, True, False, mode,
+                             return_idx=True)
+    assert np.array_equal(idx.numpy(), g["idx_" + mode])  # integer indices bit-exact
+    close(out, g["out_" + mode])
+    d2, _ = O.knn(16, T(g["xyz"]), T(g["coords"]), mode)
+    ref_d = g["dist_" + mode]
+    close(np.sqrt(d2.numpy()) if mode == "exact" else d2, ref_d, rtol=1e-6)
+
+
+def test_corr_sample_groups_xyz(golden):
+    g = golden("corr_sample_small")
+    out = O.corr_sample(T(g["xyz"]), T(g["fvec"]), T(g["targets"]), T(g["coords"]), 8, 4, True, True, "exact")
+    close(out, g["out_exact_k8_g4_xyz"])
+
+
+@pytest.mark.parametrize("r", [3, 4])
+def test_window_corr(golden, r):
+    g = golden("window_corr_small")
+    pyr = O.window_corr_pyramid(T(g["fmaps"]), 3)
+    close(O.window_corr_sample(pyr, T(g["targets"]), T(g["coords"]), r), g[f"out_r{r}"])
+
+
+def test_embeddings(golden):
+    g = golden("embeddings")
+    pe = O.pos_embed_3d(582, T(g["coords0"]).reshape(-1, 3))
+    assert np.array_equal(pe.numpy(), g["pos_embed"].reshape(-1, 582))  # float64, bit-exact
+    te = O.sincos_1d(582, (torch.linspace(0, 11, 12).reshape(12, 1) / 12).numpy())
+    assert np.array_equal(te, g["times_embed"])
+    close(O.flow_embedding(T(g["flows"]), 64), g["flow_embed"], rtol=0, atol=0)
+
+
+def test_updateformer(golden, W):
+    g = golden("updateformer_16x12")
+    close(O.update_former(W, T(g["x"]), CFG), g["out"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["cdist", "exact"])
+def test_refine_window(golden, W, mode):
+    g = golden("refine_window_small")
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=12, H=128, W=128, N=12)
+    fm = O.encoder(W, 2 * (T(clip["rgbs"]).reshape(-1, 3, 128, 128) / 255.0) - 1).reshape(1, 2, 12, 128, 32, 32)
+    d = torch.nn.functional.interpolate(T(clip["depths"]).reshape(-1, 1, 128, 128), scale_factor=0.25, mode="nearest")
+    q = T(clip["query_points"])
+    n = q.shape[1]
+    preds, vis = O.refine_window(W, CFG, fm, d.reshape(1, 2, 12, 1, 32, 32), T(clip["intrs"]), T(clip["extrs"]),
+                                 q[:, None, :, 1:].repeat(1, 12, 1, 1), torch.full((1, 12, n, 1), 10.0),
+                                 torch.ones(1, 12, n, 1, dtype=torch.bool), T(g["feat_init"]), iters=3, knn_mode=mode)
+    close(torch.stack(preds), g["coords_" + mode], rtol=1e-4, atol=1e-5)
+    close(vis, g["vis_" + mode], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["e2e_tiny", "e2e_two_windows", "e2e_short_clip"])
+@pytest.mark.parametrize("mode", ["cdist", "exact"])
+def test_end_to_end(golden, W, name, mode):
+    g = golden(name)
+    kw = dict(seed=int(g["seed"]), V=int(g["V"]), T=int(g["T"]), H=int(g["H"]), W=int(g["W"]), N=int(g["N"]))
+    if "late_queries" in g.files:
+        kw.update(late_queries=bool(g["late_queries"]), query_frames=tuple(int(x) for x in g["query_frames"]))
+    clip = synth.make_clip(**kw)
+    r = O.tracker_forward(W, CFG, T(clip["rgbs"]), T(clip["depths"]), T(clip["query_points"]), T(clip["intrs"]),
+                          T(clip["extrs"]), iters=4, knn_mode=mode)
+    assert len(r["windows"]) == int(g["n_windows"])
+    ref = g["traj_" + mode]
+    rel = np.abs(r["traj_e"].numpy() - ref).max() / np.abs(ref).max()
+    assert rel < 1e-4, rel  # north-star tolerance: tracks within 1e-4 relative
+    close(r["vis_e"], g["vis_" + mode], rtol=0, atol=1e-3)
+    close(r["feat_init"], g["feat_init_" + mode], rtol=1e-4, atol=1e-5)
+    inv, srt = r["inv_sort_inds"], r["sort_inds"]
+    assert torch.equal(inv[srt], torch.arange(len(srt)))  # appendix D: inverse-permutation property
+
+
+def test_predictor(golden, W):
+    g = golden("predictor_small")
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=12, H=160, W=192, N=5)
+    args = [T(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
+    rg, dp, intr, support = O.predictor_prepare(*args, interp_shape=(128, 160), grid_size=3, n_grids_per_view=2)
+    q = torch.cat([args[2], support], 1)
+    close(q, g["model_query_points"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(q[0, :, 0].long().numpy(), g["model_query_points"][0, :, 0].astype(np.int64))
+    close(intr, g["model_intrs"])
+    assert np.array_equal(dp[0, :, :, 0, ::8, ::8].numpy(), g["depths_sample"])
+    assert np.array_equal(rg[0, :, :, :, ::8, ::8].numpy(), g["rgbs_sample"])
+    r = O.predictor_forward(W, CFG, *args, interp_shape=(128, 160), grid_size=3, n_grids_per_view=2, n_iters=2)
+    ref = g["traj_e"]
+    assert np.abs(r["traj_e"].numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    close(r["vis_e_as_prob"], g["vis_e_as_prob"], rtol=0, atol=1e-3)
+    assert r["vis_e"].dtype == torch.bool
+
+
+def test_helpers(golden):
+    g = golden("helpers")
+    pix, z = O.project_to_view(T(g["world"]), T(g["intrs"]), T(g["extrs"]))
+    close(pix, g["pix"])
+    close(z, g["z"])
+    close(O.bilinear_sample2d(T(g["im"]), T(g["xs"]), T(g["ys"])), g["bil"])
+    close(O.grid_points(5, (48, 64)), g["grid5"])
+    close(O.grid_points(3, (50, 50), center=(20.5, 31.25)), g["grid3c"])
