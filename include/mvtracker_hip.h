@@ -1,0 +1,187 @@
+/*
+ * mvtracker_hip.h -- C ABI of libmvtracker_hip.so, the MI355X (gfx950) implementation of the
+ * multi-view point-tracking forward path.
+ *
+ * The reference (samiazirar/mvtracker) is pure Python on torch ATen; it has no FFI of its own
+ * for this path.  The entry points below are the set of operations its hot path performs
+ * (SURVEY.md section 8a/8b); each one names the reference code it replaces (paths relative to
+ * the reference root).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 / int32 / uint64 data unless marked "host";
+ *     tensors are dense row-major with the layouts stated per function;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
+ *     asynchronously on it; no entry point allocates, frees or synchronises;
+ *   - return value: 0 = ok, MVT_ERR_ARG = rejected arguments (nothing launched),
+ *     1000 + hipError_t = launch failure; no exceptions, no global state, re-entrant per stream;
+ *   - inputs are borrowed and never written; outputs are fully overwritten unless stated.
+ *
+ * Internal clip layout ("frame store"): features of pyramid level l are kept frame-major as
+ *   fvec_l [T][V][h_l][w_l][C]  (fp32, channels last), xyz_l [T][V][h_l][w_l][4] (x,y,z,0),
+ * so the fused point cloud of frame t (reference: init_pointcloud_from_rgbd,
+ * mvtracker/models/core/model_utils.py:420-482, layout (B*S, V*H*W, C)) is the contiguous slice
+ * [t] with P_l = V*h_l*w_l points.  Track state is track-major: coords [N][S][3],
+ * ffeats [N][S][C], tokens [N][S][D].
+ */
+#ifndef MVTRACKER_HIP_H
+#define MVTRACKER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVT_OK 0
+#define MVT_ERR_ARG 1
+#define MVT_ERR_HIP_BASE 1000
+
+/* activation codes of mvt_gemm / mvt_conv2d epilogues */
+#define MVT_ACT_NONE 0
+#define MVT_ACT_RELU 1
+#define MVT_ACT_GELU_TANH 2 /* nn.GELU(approximate="tanh"), cotracker2/blocks.py:289 */
+#define MVT_ACT_GELU_ERF 3  /* nn.GELU(), mvtracker.py:179 */
+
+/* library / device introspection (host) */
+int mvt_abi_version(void);
+const char* mvt_build_arch(void); /* "gfx950" */
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense GEMM on the matrix cores (fp32 MFMA 32x32x2, exact fp32 FMA chains).
+ *   C[M][ldc] = R[M][ldr] (optional) + act(A[M][lda] . Wt[N][ldw]^T + bias[N] (optional))
+ * A rows must be readable for round_up(K,4) floats; Wt is the torch nn.Linear weight layout
+ * [out][in] repacked so that ldw = round_up(K,32) with zero padding.  Replaces every
+ * nn.Linear of the updater (cotracker2/blocks.py:55-67, 254-271, 364-382, 456, 489) and
+ * ffeats_updater (mvtracker.py:179, 396).  R may alias C.
+ * --------------------------------------------------------------------------------------------- */
+int mvt_gemm(const float* A, int lda, const float* Wt, int ldw, const float* bias, const float* R, int ldr,
+             float* C, int ldc, int M, int N, int K, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2-D convolution as implicit GEMM on the matrix cores, channels-last.
+ *   in  [n][H][W][Cin]   (Cin % 32 == 0, or Cin == 4 for the 7x7 stem with kw*4+c packing)
+ *   wt  [Cout][KH][KW][Cin] repacked from torch's [Cout][Cin][KH][KW]; for the stem
+ *       [Cout][KH][32] with element kw*4+c (c<3, kw<7) and zeros elsewhere
+ *   out [n][Ho][Wo][ldo] (ldo >= Cout; lets a conv write into a channel slice / the frame store)
+ * Zero padding `pad`, stride `stride`.  Replaces nn.Conv2d in BasicEncoder / ResidualBlock
+ * (mvtracker/models/core/spatracker/blocks.py:74-82, 116, 157-193).
+ * --------------------------------------------------------------------------------------------- */
+int mvt_conv2d(const float* in, const float* wt, const float* bias, float* out, int n, int H, int W, int Cin,
+               int Cout, int KH, int KW, int stride, int pad, int ldo, int act, void* stream);
+
+/* rgbs [V][T][3][H][W] (values 0..255) -> x [T_sel][V][H][W][4] = (2*(rgb/255)-1, 0) for frames
+ * t0..t0+nt-1 (mvtracker.py:565-567 normalisation + channels-last repack). */
+int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream);
+
+/* nearest-neighbour resize of [n][C][Hi][Wi] planes to [n][C][Ho][Wo] with torch's index rule
+ * (evaluation_predictor_3dpt.py:76-81, F.interpolate(mode="nearest")). */
+int mvt_resize_nearest(const float* in, float* out, long long planes, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* InstanceNorm2d (eps 1e-5, biased variance, no affine; blocks.py:99-103,150-152) on
+ * channels-last x [n][HW][C]:  stats -> mean_rstd [n][C][2]; `partial` is scratch of
+ * n*MVT_IN_SLABS*C*2 doubles. */
+#define MVT_IN_SLABS 64
+int mvt_instnorm_stats(const float* x, int ldx, double* partial, float* mean_rstd, int n, long long HW, int C,
+                       void* stream);
+/* y = relu((x-mean)*rstd)                                  (skip == NULL)
+ * y = relu(skip' + relu((x-mean)*rstd)), skip' = skip or (skip-mean_s)*rstd_s when skip_stats
+ * is given (ResidualBlock.forward, blocks.py:119-128).  y may alias x. */
+int mvt_instnorm_apply(const float* x, const float* mean_rstd, const float* skip, const float* skip_stats, float* y,
+                       int n, long long HW, int C, void* stream);
+
+/* bilinear resize, align_corners=True, of channels-last src [n][Hs][Ws][C] into the channel
+ * slice [c_off, c_off+C) of dst [n][Hd][Wd][ldd] (blocks.py:254-280, the 416-channel concat). */
+int mvt_resize_bilinear_ac(const float* src, float* dst, int n, int Hs, int Ws, int C, int Hd, int Wd, int ldd,
+                           int c_off, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Frame store construction (reference: init_pointcloud_from_rgbd, model_utils.py:420-482, and
+ * the depth resampling of mvtracker.py:558-562).
+ * --------------------------------------------------------------------------------------------- */
+/* intrs [n][3][3], extrs [n][3][4] (world->camera) -> kinv [n][9], einv [n][12] (rows 0..2 of the
+ * inverse 4x4), closed form in fp64 rounded to fp32 (model_utils.py:453-457). */
+int mvt_invert_cameras(const float* intrs, const float* extrs, float* kinv, float* einv, int n, void* stream);
+/* depths [V][T][H][W] -> level-0 strided depth [T][V][H/s][W/s], nearest: source pixel (s*i, s*j)
+ * (mvtracker.py:558-562). */
+int mvt_depth_subsample(const float* depths, float* out, int V, int T, int H, int W, int s, void* stream);
+/* 2x2 average pool of channels-last [n][h][w][C] -> [n][h/2][w/2][C] (model_utils.py:440). */
+int mvt_avgpool2(const float* in, float* out, long long n, int h, int w, int C, void* stream);
+/* xyz_l [T][V][h_l][w_l][4] from level-0 strided depth [T][V][hs][ws] (nearest-subsampled by
+ * 2^level, model_utils.py:443-444), pixel grid (i+0.5)*stride*2^level-0.5 (:462-466), kinv/einv
+ * indexed [v*T+t] (:467-473). */
+int mvt_unproject(const float* depth_s, const float* kinv, const float* einv, float* xyz, int V, int T, int hs,
+                  int ws, int stride, int level, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * kNN + correlation (reference: knn / PointcloudCorrBlock.corr_sample, mvtracker.py:26-90,
+ * 800-846; feature init 1-NN, mvtracker.py:627-643).
+ * --------------------------------------------------------------------------------------------- */
+/* Exact brute-force kNN.  For every (query n, slot s): candidates are the P points of frame
+ * frame_of_slot = min(frame0 + s*frame_step, T-1) of xyz [T][P][4]; query = coords[(n*S+s)*3..].
+ * d2 = fma(dz,dz,fma(dy,dy,dx*dx)), neighbours ascending by (d2, index).  The candidate range
+ * is cut into nseg segments scanned by different waves; keys [N][S][nseg][K] receive
+ * (d2 bits << 32 | index) per segment, ascending.  1 <= K <= 16, P >= K. */
+int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step,
+                 int T, int K, int nseg, unsigned long long* keys, void* stream);
+/* Gather-dot for one pyramid level: merges the nseg partial lists of mvt_knn_scan, gathers the
+ * K neighbour rows of fvec [T][P][C] (C % 4 == 0, C <= 256, groups == 1) and writes, for
+ * k < K:  out[(n*S+s)*ldo + o_off + 4k + {0,1,2,3}] = { <target, f_k>/sqrt(C), xyz_k - coord }
+ * (mvtracker.py:827-842 with corr_add_neighbor_offset=True).  targets [N][S][C].  idx_out
+ * (optional) [N][S][K] int32 receives the neighbour indices. */
+int mvt_corr_gather_dot(const float* xyz, const float* fvec, long long P, int C, const float* targets,
+                        const float* coords, const unsigned long long* keys, int N, int S, int frame0,
+                        int frame_step, int T, int K, int nseg, float* out, int ldo, int o_off, int* idx_out,
+                        void* stream);
+/* 1-NN feature init: feat_out[n][C] = fvec[frame][idx] with idx from keys [n][1][nseg][1]
+ * (mvtracker.py:640-643); idx_out optional. */
+int mvt_knn1_gather(const float* fvec, long long P, int C, const unsigned long long* keys, int n, int nseg,
+                    int frame, float* feat_out, int* idx_out, void* stream);
+
+/* Secondary operator: bilinear-window correlation (CorrBlock.corr_sample,
+ * spatracker/blocks.py:492-533 + bilinear_sampler :604-619).  fmap_l channels-last
+ * [BS][h][w][C] for ONE level; targets [BS][N][C]; coords [BS][N][2] level-0 pixels;
+ * out[(bs*N+n)*ldo + o_off + i*(2r+1)+j] for the (2r+1)^2 window around coords/2^level. */
+int mvt_window_corr(const float* fmap, const float* targets, const float* coords, float* out, int BS, int N,
+                    int C, int h, int w, int level, int radius, int ldo, int o_off, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token assembly and track update (mvtracker.py:324-349, 374-408; embeddings.py:35-50,
+ * 88-106, 134-161).
+ * --------------------------------------------------------------------------------------------- */
+/* pos [N][D] = first D entries of the 3x(dim3/3) sin|cos embedding (dim_padded wide) of coords0 (row n at
+ * coords[(n*S)*3], fp64 math, omega_j = 10000^(-j/(dim3/6))) (embeddings.py:35-50). */
+int mvt_pos_embed(const float* coords, int N, int S, int D, int dim_padded, float* pos, void* stream);
+/* x[(n*S+s)*ldx + ..] = cat[flow_embed(coords[n,s]-coords[n,0]) (3*E+3) | fcorr (Fc) |
+ * ffeats (C) | mask | vis] + pos[n] + time[s]  (mvtracker.py:379-386). */
+int mvt_token_assemble(const float* coords, const float* fcorr, int Fc, const float* ffeats, int C,
+                       const float* mask_vis, const float* pos, const float* time_embed, int N, int S, int E,
+                       float* x, int ldx, void* stream);
+/* delta [N*S][ldd] -> coords += delta[:, 0:3]; dn [N*S][C] = GroupNorm(1,C)(delta[:, 3:3+C])
+ * (eps 1e-5, affine gw/gb) (mvtracker.py:392-395, 398).  nan_flag (optional int*) is set to 1
+ * if any updated coordinate is NaN (deferred form of the guard at :401-404). */
+int mvt_delta_split(const float* delta, int ldd, const float* gw, const float* gb, float* coords, float* dn,
+                    long long rows, int C, int* nan_flag, void* stream);
+/* out[r] = <x[r][0:C], w> + b  (vis_predictor, mvtracker.py:180, 408). */
+int mvt_rowdot(const float* x, int ldx, const float* w, const float* b, float* out, long long rows, int C,
+               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Updater transformer pieces (cotracker2/blocks.py:246-337, 455-494).
+ * --------------------------------------------------------------------------------------------- */
+/* y[r] = LayerNorm(x[r][0:C]) * w + b (w,b optional), biased variance, given eps (:284-287, 314-315). */
+int mvt_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, long long rows,
+                  int C, float eps, void* stream);
+/* softmax(q k^T / sqrt(dh)) v for `groups` independent groups, `heads` heads of width dh <= 64.
+ * Row r of query item i in group g is  q + (g*q_gs + i*q_is) * ldq  (+ head*dh); likewise k, v, o.
+ * One wave per (group, head, query); keys on lanes, online softmax in fp32
+ * (FlashAttention.forward, blocks.py:258-271, attn_mask None). */
+int mvt_attention(const float* q, int ldq, long long q_gs, long long q_is, const float* k, const float* v,
+                  int ldkv, long long k_gs, long long k_is, float* o, int ldo, int groups, int nq, int nk,
+                  int heads, int dh, void* stream);
+/* x[(n*S+s)*ld + 0:C] = v[n][0:C] for all s  (virtual-token broadcast, blocks.py:458-459). */
+int mvt_broadcast_rows(const float* v, float* x, int ld, int n, int S, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVTRACKER_HIP_H */

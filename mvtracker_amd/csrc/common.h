@@ -1,0 +1,71 @@
+// Shared helpers for the gfx950 kernels of libmvtracker_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvtracker_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MVT_WAVE 64
+
+#define MVT_REQUIRE(cond) \
+  do {                    \
+    if (!(cond)) return MVT_ERR_ARG; \
+  } while (0)
+
+static inline int mvt_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MVT_OK : MVT_ERR_HIP_BASE + (int)e;
+}
+
+static inline hipStream_t mvt_stream(void* s) { return (hipStream_t)s; }
+
+static inline long long mvt_cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float mvt_gelu_tanh(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float inner = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+__device__ __forceinline__ float mvt_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+__device__ __forceinline__ float mvt_act(float x, int act) {
+  switch (act) {
+    case MVT_ACT_RELU: return fmaxf(x, 0.0f);
+    case MVT_ACT_GELU_TANH: return mvt_gelu_tanh(x);
+    case MVT_ACT_GELU_ERF: return mvt_gelu_erf(x);
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = __shfl_xor(lo, o, 64);
+  hi = __shfl_xor(hi, o, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long w = shfl_xor_u64(v, o);
+    v = w < v ? w : v;
+  }
+  return v;
+}

@@ -1,0 +1,211 @@
+// HBM-bound encoder-side kernels: input repack, nearest / align-corners bilinear resize,
+// InstanceNorm statistics and the fused normalise + ReLU (+ residual) pass.  All tensors are
+// channels-last; every thread moves 16 bytes.
+#include "common.h"
+
+namespace {
+
+__global__ void rgb_to_nhwc4_kernel(const float* __restrict__ rgbs, float* __restrict__ out, int V, int T, int H, int W,
+                                    int t0, int nt) {
+  const long long hw = (long long)H * W;
+  const long long total = (long long)nt * V * hw;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long img = i / hw;
+    long long pix = i - img * hw;
+    int tt = (int)(img / V), v = (int)(img - (long long)tt * V);
+    const float* src = rgbs + (((long long)v * T + (t0 + tt)) * 3) * hw + pix;
+    f32x4 o;
+    o[0] = 2.0f * (src[0] / 255.0f) - 1.0f;
+    o[1] = 2.0f * (src[hw] / 255.0f) - 1.0f;
+    o[2] = 2.0f * (src[2 * hw] / 255.0f) - 1.0f;
+    o[3] = 0.0f;
+    *reinterpret_cast<f32x4*>(out + i * 4) = o;
+  }
+}
+
+__global__ void resize_nearest_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes, int Hi, int Wi,
+                                      int Ho, int Wo) {
+  // torch nearest: src = min(floor(dst * (float)in/out), in - 1)
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  const long long total = planes * Ho * Wo;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int x = (int)(i % Wo);
+    long long r = i / Wo;
+    int y = (int)(r % Ho);
+    long long pl = r / Ho;
+    int sy = min((int)floorf(y * sh), Hi - 1);
+    int sx = min((int)floorf(x * sw), Wi - 1);
+    out[i] = in[(pl * Hi + sy) * (long long)Wi + sx];
+  }
+}
+
+// stage 1: block (slab, image) sums channel quads over its pixel slab in fp64
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, int ldx, double* __restrict__ partial,
+                                                               long long HW, int C) {
+  __shared__ double red[256 * 8];
+  const int slab = blockIdx.x, img = blockIdx.y;
+  const int cq = C / 4;              // channel quads per pixel
+  const int lanes = 256 / cq;        // pixel lanes (cq <= 64 -> lanes >= 4)
+  const int t = threadIdx.x;
+  const int q = t % cq, pl = t / cq;
+  const long long per = (HW + MVT_IN_SLABS - 1) / MVT_IN_SLABS;
+  const long long p0 = slab * per, p1 = min(HW, p0 + per);
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  if (pl < lanes) {
+    const float* base = x + (long long)img * HW * ldx + q * 4;
+    for (long long p = p0 + pl; p < p1; p += lanes) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(base + p * ldx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[e] += (double)v[e];
+        ss[e] += (double)v[e] * (double)v[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[t * 8 + e] = s[e];
+    red[t * 8 + 4 + e] = ss[e];
+  }
+  __syncthreads();
+  if (t < cq) {  // fixed-order reduction over pixel lanes -> deterministic
+    double a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0;
+    for (int l = 0; l < lanes; ++l)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += red[(l * cq + t) * 8 + e];
+    double* dst = partial + (((long long)img * MVT_IN_SLABS + slab) * C + t * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dst[e * 2] = a[e];
+      dst[e * 2 + 1] = a[4 + e];
+    }
+  }
+}
+
+__global__ void instnorm_finish_kernel(const double* __restrict__ partial, float* __restrict__ mean_rstd, long long HW, int C,
+                                       long long total) {
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;  // (img, c)
+  if (i >= total) return;
+  long long img = i / C;
+  int c = (int)(i - img * C);
+  double s = 0, ss = 0;
+  for (int slab = 0; slab < MVT_IN_SLABS; ++slab) {
+    const double* p = partial + ((img * MVT_IN_SLABS + slab) * C + c) * 2;
+    s += p[0];
+    ss += p[1];
+  }
+  double mean = s / (double)HW;
+  double var = ss / (double)HW - mean * mean;
+  if (var < 0) var = 0;
+  mean_rstd[i * 2] = (float)mean;
+  mean_rstd[i * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+__global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ st, const float* __restrict__ skip,
+                                      const float* __restrict__ skst, float* __restrict__ y, long long HW, int C, long long total4) {
+  const int cq = C / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    int q = (int)(i % cq);
+    long long img = (i / cq) / HW;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    const float* s = st + (img * C + q * 4) * 2;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[e] - s[e * 2]) * s[e * 2 + 1], 0.0f);
+    if (skip) {
+      f32x4 k = *reinterpret_cast<const f32x4*>(skip + i * 4);
+      if (skst) {
+        const float* ks = skst + (img * C + q * 4) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k[e] = (k[e] - ks[e * 2]) * ks[e * 2 + 1];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(k[e] + o[e], 0.0f);
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+__global__ void resize_bilinear_ac_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int Hs, int Ws, int C, int Hd,
+                                          int Wd, int ldd, int c_off) {
+  // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1)
+  const float rh = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
+  const float rw = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+  const int cq = C / 4;
+  const long long total = (long long)n * Hd * Wd * cq;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int q = (int)(i % cq);
+    long long pix = i / cq;
+    int x = (int)(pix % Wd);
+    long long r = pix / Wd;
+    int y = (int)(r % Hd);
+    long long img = r / Hd;
+    float fy = rh * y, fx = rw * x;
+    int y0 = (int)fy, x0 = (int)fx;
+    int yp = y0 < Hs - 1 ? 1 : 0, xp = x0 < Ws - 1 ? 1 : 0;
+    float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = src + ((img * Hs + y0) * (long long)Ws + x0) * C + q * 4;
+    f32x4 a00 = *reinterpret_cast<const f32x4*>(b);
+    f32x4 a01 = *reinterpret_cast<const f32x4*>(b + (long long)xp * C);
+    f32x4 a10 = *reinterpret_cast<const f32x4*>(b + (long long)yp * Ws * C);
+    f32x4 a11 = *reinterpret_cast<const f32x4*>(b + ((long long)yp * Ws + xp) * C);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = hy * (hx * a00[e] + lx * a01[e]) + ly * (hx * a10[e] + lx * a11[e]);
+    *reinterpret_cast<f32x4*>(dst + pix * ldd + c_off + q * 4) = o;
+  }
+}
+
+inline unsigned grid_for(long long total, int block = 256) {
+  long long g = mvt_cdiv(total, block);
+  return (unsigned)(g > 256 * 32 ? 256 * 32 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream) {
+  MVT_REQUIRE(rgbs && out && V > 0 && T > 0 && H > 0 && W > 0 && t0 >= 0 && nt > 0 && t0 + nt <= T);
+  long long total = (long long)nt * V * H * W;
+  hipLaunchKernelGGL(rgb_to_nhwc4_kernel, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), rgbs, out, V, T, H, W, t0, nt);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_resize_nearest(const float* in, float* out, long long planes, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  MVT_REQUIRE(in && out && planes > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for(planes * Ho * Wo)), dim3(256), 0, mvt_stream(stream), in, out, planes, Hi,
+                     Wi, Ho, Wo);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_instnorm_stats(const float* x, int ldx, double* partial, float* mean_rstd, int n, long long HW, int C,
+                                  void* stream) {
+  MVT_REQUIRE(x && partial && mean_rstd && n > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 256 && ldx >= C && ldx % 4 == 0);
+  MVT_REQUIRE(256 % (C / 4) == 0 || C / 4 <= 64);
+  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(MVT_IN_SLABS, n), dim3(256), 0, mvt_stream(stream), x, ldx, partial, HW, C);
+  long long total = (long long)n * C;
+  hipLaunchKernelGGL(instnorm_finish_kernel, dim3((unsigned)mvt_cdiv(total, 256)), dim3(256), 0, mvt_stream(stream), partial,
+                     mean_rstd, HW, C, total);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_instnorm_apply(const float* x, const float* mean_rstd, const float* skip, const float* skip_stats, float* y,
+                                  int n, long long HW, int C, void* stream) {
+  MVT_REQUIRE(x && mean_rstd && y && n > 0 && HW > 0 && C > 0 && C % 4 == 0);
+  MVT_REQUIRE(skip || !skip_stats);
+  long long total4 = (long long)n * HW * (C / 4);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, mvt_stream(stream), x, mean_rstd, skip, skip_stats,
+                     y, HW, C, total4);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_resize_bilinear_ac(const float* src, float* dst, int n, int Hs, int Ws, int C, int Hd, int Wd, int ldd,
+                                      int c_off, void* stream) {
+  MVT_REQUIRE(src && dst && n > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && C % 4 == 0);
+  MVT_REQUIRE(ldd % 4 == 0 && c_off % 4 == 0 && c_off >= 0 && c_off + C <= ldd);
+  long long total = (long long)n * Hd * Wd * (C / 4);
+  hipLaunchKernelGGL(resize_bilinear_ac_kernel, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), src, dst, n, Hs, Ws, C, Hd,
+                     Wd, ldd, c_off);
+  return mvt_launch_status();
+}

@@ -1,0 +1,249 @@
+// fp32 GEMM / implicit-GEMM convolution on the CDNA4 matrix cores.
+//
+// One kernel body serves every nn.Linear of the updater and every nn.Conv2d of the encoder:
+//   C[m][n] = R[m][n] + act( sum_k A(m,k) * Wt[n][k] + bias[n] )
+// A(m,k) comes from a pluggable row loader: dense rows (mode 0), an NHWC im2col gather with
+// Cin % 32 == 0 (mode 1: one 32-wide k-tile lies inside a single filter tap, so a tile row is 128
+// contiguous bytes of the input) or the 7x7 stem with Cin padded to 4 (mode 2: one k-tile per
+// filter row, 7 pixels x 4 channels contiguous).
+//
+// Matrix-core mapping: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD).  A wave
+// owns TMx TN blocks of 32x32; lanes 0-31 feed k, lanes 32-63 feed k+4 of each 8-wide k-group so
+// that one ds_read_b128 per operand block serves four consecutive MFMAs (the k permutation is
+// the same for A and B, so the sum is unchanged).  LDS tiles are [rows][32+4] floats: the 144-byte
+// row stride makes the 16-lane ds_read_b128 groups conflict-free and keeps ds_write_b128 aligned.
+// Global loads for k-tile t+1 are issued into registers before the MFMAs of tile t.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+  const float* A;
+  const float* W;
+  const float* bias;
+  const float* R;
+  float* C;
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  int act;
+  int mode;  // 0 dense, 1 conv (Cin % 32 == 0), 2 stem (Cin == 4)
+  int H, Wd, Cin, Ho, Wo, KH, KW, stride, pad;
+  int nk;  // number of 32-wide k tiles
+};
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_mfma_f32(GemmArgs p) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int AF = BM / 32;  // float4 per thread per k-tile (A)
+  constexpr int BF = BN / 32;  // float4 per thread per k-tile (W)
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
+  float* As = lds;
+  float* Bs = lds + BM * LDS_LD;
+
+  const int t = threadIdx.x;
+  const int c4 = t & 7;
+  const int rbase = t >> 3;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x % tiles_n;
+  const long long m0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- per-row loader state (rows are fixed over the k loop)
+  const float* a_ptr[AF];
+  unsigned a_hw[AF];  // conv: (ih0 + 32000) << 16 | (iw0 + 64); dense: 1 = row valid, 0 = not
+#pragma unroll
+  for (int i = 0; i < AF; ++i) {
+    long long m = m0 + rbase + 32 * i;
+    bool ok = m < p.M;
+    if (p.mode == 0) {
+      a_ptr[i] = p.A + (ok ? m : 0) * (long long)p.lda + c4 * 4;
+      a_hw[i] = ok ? 1 : 0;
+    } else {
+      long long hw = (long long)p.Ho * p.Wo;
+      long long img = ok ? m / hw : 0;
+      int rem = ok ? (int)(m - img * hw) : 0;
+      int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+      int ih0 = ok ? oh * p.stride - p.pad : -20000;
+      int iw0 = ow * p.stride - p.pad;
+      a_ptr[i] = p.A + img * (long long)p.H * p.Wd * p.Cin;
+      a_hw[i] = ((unsigned)(ih0 + 32000) << 16) | (unsigned)(iw0 + 64);
+    }
+  }
+  const float* w_ptr[BF];
+  bool w_ok[BF];
+#pragma unroll
+  for (int i = 0; i < BF; ++i) {
+    int n = n0 + rbase + 32 * i;
+    w_ok[i] = n < p.N;
+    w_ptr[i] = p.W + (long long)(w_ok[i] ? n : 0) * p.ldw + c4 * 4;
+  }
+  const int kp4 = (p.K + 3) & ~3;
+
+  f32x4 ra[AF], rb[BF];
+  auto load_tile = [&](int kt) {
+    if (p.mode == 0) {
+      const int k = kt * BK + c4 * 4;
+      const bool kok = k < kp4;
+#pragma unroll
+      for (int i = 0; i < AF; ++i) {
+        ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kok && a_hw[i]) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
+      }
+    } else if (p.mode == 1) {
+      const int k0 = kt * BK;
+      const int tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+      for (int i = 0; i < AF; ++i) {
+        int ih = (int)(a_hw[i] >> 16) - 32000 + kh;
+        int iw = (int)(a_hw[i] & 0xFFFFu) - 64 + kw;
+        ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
+          ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((long long)ih * p.Wd + iw) * p.Cin + c0 + c4 * 4);
+      }
+    } else {
+      const int kh = kt;
+#pragma unroll
+      for (int i = 0; i < AF; ++i) {
+        int ih = (int)(a_hw[i] >> 16) - 32000 + kh;
+        int iw = (int)(a_hw[i] & 0xFFFFu) - 64 + c4;
+        ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c4 < p.KW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
+          ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((long long)ih * p.Wd + iw) * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BF; ++i) {
+      rb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (w_ok[i]) rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + kt * BK);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AF; ++i) *reinterpret_cast<f32x4*>(&As[(rbase + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BF; ++i) *reinterpret_cast<f32x4*>(&Bs[(rbase + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
+  };
+
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const bool more = kt + 1 < p.nk;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int k8 = 0; k8 < BK / 8; ++k8) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const f32x4*>(&As[((wm * TM + i) * 32 + r) * LDS_LD + k8 * 8 + h * 4]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + j) * 32 + r) * LDS_LD + k8 * 8 + h * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane holds column n0 + .. + r, rows (reg&3) + 8*(reg>>2) + 4*h of each 32x32 block
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + r;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        long long m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < p.M) {
+          float v = mvt_act(acc[i][j][e] + bv, p.act);
+          if (p.R) v += p.R[m * p.ldr + n];
+          p.C[m * p.ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t s) {
+  auto blocks = [&](int bm, int bn) { return (unsigned)(mvt_cdiv(a.M, bm) * mvt_cdiv(a.N, bn)); };
+  if (a.N % 128 != 0 && a.N % 96 == 0) {
+    hipLaunchKernelGGL((gemm_mfma_f32<1, 3, 4, 1>), dim3(blocks(128, 96)), dim3(256), 0, s, a);
+  } else if (a.N <= 64) {
+    hipLaunchKernelGGL((gemm_mfma_f32<2, 2, 4, 1>), dim3(blocks(256, 64)), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((gemm_mfma_f32<2, 2, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, s, a);
+  }
+  return mvt_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mvt_gemm(const float* A, int lda, const float* Wt, int ldw, const float* bias, const float* R, int ldr,
+                        float* C, int ldc, int M, int N, int K, int act, void* stream) {
+  MVT_REQUIRE(A && Wt && C && M > 0 && N > 0 && K > 0);
+  MVT_REQUIRE(lda % 4 == 0 && lda >= ((K + 3) & ~3));
+  MVT_REQUIRE(ldw % 32 == 0 && ldw >= ((K + 31) & ~31) && ldc >= N && (!R || ldr >= N));
+  MVT_REQUIRE(act >= 0 && act <= 3);
+  MVT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)Wt % 16 == 0));
+  GemmArgs a{};
+  a.A = A; a.W = Wt; a.bias = bias; a.R = R; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.act = act;
+  a.mode = 0;
+  a.nk = (K + BK - 1) / BK;
+  return launch_gemm(a, mvt_stream(stream));
+}
+
+extern "C" int mvt_conv2d(const float* in, const float* wt, const float* bias, float* out, int n, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad, int ldo, int act, void* stream) {
+  MVT_REQUIRE(in && wt && out && n > 0 && H > 0 && W > 0 && Cout > 0);
+  MVT_REQUIRE(KH >= 1 && KH <= 7 && KW >= 1 && KW <= 7 && stride >= 1 && stride <= 2 && pad >= 0 && pad <= 3);
+  MVT_REQUIRE(H < 16384 && W < 16384 && ldo >= Cout && act >= 0 && act <= 3);
+  MVT_REQUIRE((Cin % 32 == 0) || (Cin == 4));
+  MVT_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)wt % 16 == 0));
+  const int Ho = (H + 2 * pad - KH) / stride + 1;
+  const int Wo = (W + 2 * pad - KW) / stride + 1;
+  MVT_REQUIRE(Ho > 0 && Wo > 0);
+  const long long M = (long long)n * Ho * Wo;
+  MVT_REQUIRE(M < (1LL << 31));
+  GemmArgs a{};
+  a.A = in; a.W = wt; a.bias = bias; a.R = nullptr; a.C = out;
+  a.M = (int)M; a.N = Cout; a.ldc = ldo; a.ldr = 0; a.act = act;
+  a.H = H; a.Wd = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  if (Cin == 4) {
+    a.mode = 2; a.nk = KH; a.K = KH * 32; a.ldw = KH * 32;
+  } else {
+    a.mode = 1; a.K = KH * KW * Cin; a.nk = a.K / BK; a.ldw = a.K;
+  }
+  a.lda = 0;
+  return launch_gemm(a, mvt_stream(stream));
+}

@@ -1,0 +1,321 @@
+// Exact kNN over the fused feature point cloud and the gather-dot correlation that consumes it
+// (reference: knn / PointcloudCorrBlock.corr_sample, mvtracker.py:26-90, 800-846).
+//
+// knn_scan   - VALU-bound brute force.  A wave owns Q queries (wave-uniform registers) and
+//              streams its candidate segment 64 points per step (one float4 per lane, 1 KiB
+//              coalesced).  A candidate survives for query i when d2 <= thr_i (the current K-th
+//              best); survivors are compacted into a per-query LDS list (ballot + mbcnt) and the
+//              list is reduced to its K smallest (d2,index) keys whenever it could overflow, which
+//              tightens thr_i.  After a warm-up almost every step is 7 VALU + 1 compare per query.
+// corr_gather_dot - HBM-bound.  One wave per (track, frame): merge the per-segment key lists,
+//              gather the K neighbour rows (C floats each, two rows per 1-KiB wave load, all loads
+//              in flight together), dot them with the track feature by half-wave shuffle
+//              reductions, append the neighbour offsets.
+#include "common.h"
+
+namespace {
+
+constexpr unsigned long long KEY_MAX = ~0ULL;
+constexpr int CAP = 128;  // per-query LDS list capacity (keys)
+
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Reduce the first `cnt` keys of `list` to the K smallest, sorted ascending into list[0..K-1].
+// Returns the K-th smallest key (KEY_MAX if cnt < K).  One wave; cnt <= CAP.
+__device__ __forceinline__ unsigned long long select_k(unsigned long long* list, int cnt, int K, int lane) {
+  unsigned long long e0 = lane < cnt ? list[lane] : KEY_MAX;
+  unsigned long long e1 = 64 + lane < cnt ? list[64 + lane] : KEY_MAX;
+  unsigned long long mine = KEY_MAX, last = KEY_MAX;
+  for (int r = 0; r < K; ++r) {
+    unsigned long long m = wave_min_u64(e0 < e1 ? e0 : e1);
+    if (e0 == m) e0 = KEY_MAX;  // indices are unique, so at most one live entry matches (KEY_MAX stays KEY_MAX)
+    else if (e1 == m) e1 = KEY_MAX;
+    if (lane == r) mine = m;
+    last = m;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < K) list[lane] = mine;
+  __builtin_amdgcn_wave_barrier();
+  return last;
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ xyz, long long P, const float* __restrict__ coords,
+                                                       int N, int S, int frame0, int frame_step, int T, int K, int nseg,
+                                                       unsigned long long* __restrict__ keys, int qgroups) {
+  __shared__ unsigned long long lds[4 * Q * CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // task id -> (segment, query group, slot); segment fastest so that heavy frames spread over CUs
+  long long task = (long long)blockIdx.x * 4 + wave;
+  const long long ntask = (long long)qgroups * S * nseg;
+  if (task >= ntask) return;
+  const int seg = (int)(task % nseg);
+  const int qg = (int)((task / nseg) % qgroups);
+  const int s = (int)(task / ((long long)nseg * qgroups));
+  int frame = frame0 + s * frame_step;
+  frame = frame < T - 1 ? frame : T - 1;
+  const float* cand = xyz + (long long)frame * P * 4;
+  const long long per = (P + nseg - 1) / nseg;
+  const long long c0 = seg * per;
+  const long long c1 = c0 + per < P ? c0 + per : P;
+
+  unsigned long long* list = lds + (long long)wave * Q * CAP;
+  float qx[Q], qy[Q], qz[Q], thr[Q];
+  int cnt[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    const int n = qg * Q + i;
+    const float* c = coords + ((long long)(n < N ? n : N - 1) * S + s) * 3;
+    qx[i] = uniform_f(c[0]);
+    qy[i] = uniform_f(c[1]);
+    qz[i] = uniform_f(c[2]);
+    thr[i] = __int_as_float(0x7f800000);  // +inf
+    cnt[i] = 0;
+  }
+  const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
+
+  long long c = c0 + lane;
+  f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (c < c1) p = *reinterpret_cast<const f32x4*>(cand + c * 4);
+  for (long long base = c0; base < c1; base += 64) {
+    const long long cn = base + 64 + lane;
+    f32x4 pn = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (cn < c1) pn = *reinterpret_cast<const f32x4*>(cand + cn * 4);  // prefetch next step
+    const bool live = c < c1;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      const float dx = p[0] - qx[i], dy = p[1] - qy[i], dz = p[2] - qz[i];
+      const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+      const bool pass = live && (d2 <= thr[i]);
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        unsigned long long* l = list + i * CAP;
+        if (pass) l[cnt[i] + __popcll(m & lt_mask)] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
+        cnt[i] += __popcll(m);
+        if (cnt[i] > CAP - 64) {
+          __builtin_amdgcn_wave_barrier();
+          unsigned long long kth = select_k(l, cnt[i], K, lane);
+          cnt[i] = K;
+          thr[i] = __uint_as_float((unsigned)(kth >> 32));
+        }
+      }
+    }
+    p = pn;
+    c = cn;
+  }
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    const int n = qg * Q + i;
+    unsigned long long* l = list + i * CAP;
+    __builtin_amdgcn_wave_barrier();
+    select_k(l, cnt[i], K, lane);
+    if (n < N && lane < K) {
+      unsigned long long v = lane < cnt[i] ? l[lane] : KEY_MAX;
+      keys[(((long long)n * S + s) * nseg + seg) * K + lane] = v;
+    }
+  }
+}
+
+// lanes [0, E) hold keys; returns in lane r (r < K) the r-th smallest.  E <= 64.
+__device__ __forceinline__ unsigned long long merge_keys(unsigned long long e, int K, int lane) {
+  unsigned long long mine = KEY_MAX;
+  for (int r = 0; r < K; ++r) {
+    unsigned long long m = wave_min_u64(e);
+    if (e == m) e = KEY_MAX;
+    if (lane == r) mine = m;
+  }
+  return mine;
+}
+
+template <int LPR>  // lanes per feature row: C = 4 * LPR
+__global__ __launch_bounds__(256) void corr_gather_dot_kernel(const float* __restrict__ xyz, const float* __restrict__ fvec, long long P,
+                                                              const float* __restrict__ targets, const float* __restrict__ coords,
+                                                              const unsigned long long* __restrict__ keys, int N, int S, int frame0,
+                                                              int frame_step, int T, int K, int nseg, float* __restrict__ out, int ldo,
+                                                              int o_off, int* __restrict__ idx_out) {
+  constexpr int C = 4 * LPR;
+  constexpr int RPL = 64 / LPR;  // rows per wave load
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // n * S + s
+  if (row >= (long long)N * S) return;
+  const int s = (int)(row % S);
+  int frame = frame0 + s * frame_step;
+  frame = frame < T - 1 ? frame : T - 1;
+
+  const int E = nseg * K;
+  unsigned long long key = lane < E ? keys[row * E + lane] : KEY_MAX;
+  if (nseg > 1) key = merge_keys(key, K, lane);
+  unsigned idx = (unsigned)key;
+  if ((long long)idx >= P) idx = (unsigned)(P - 1);  // only reachable with NaN coordinates; stay in bounds
+  if (idx_out && lane < K) idx_out[row * K + lane] = (int)idx;
+
+  const int sub = lane / LPR, cq = lane % LPR;
+  const f32x4 tg = *reinterpret_cast<const f32x4*>(targets + row * C + cq * 4);
+  const float* fbase = fvec + (long long)frame * P * C + cq * 4;
+  constexpr int MAXJ = 16 / RPL;
+  f32x4 f[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int k = j * RPL + sub;
+    const unsigned ik = __shfl(idx, k < K ? k : 0, 64);
+    f[j] = *reinterpret_cast<const f32x4*>(fbase + (long long)ik * C);
+  }
+  // neighbour offsets (lane k < K)
+  const f32x4 nx = *reinterpret_cast<const f32x4*>(xyz + ((long long)frame * P + idx) * 4);
+  const float* cw = coords + row * 3;
+  const float ox = nx[0] - cw[0], oy = nx[1] - cw[1], oz = nx[2] - cw[2];
+
+  const float scale = sqrtf((float)C);
+  float mine = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    float d = tg[0] * f[j][0];
+    d = fmaf(tg[1], f[j][1], d);
+    d = fmaf(tg[2], f[j][2], d);
+    d = fmaf(tg[3], f[j][3], d);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    // lane k takes the value of its (j, sub) = (k / RPL, k % RPL)
+    const float v = __shfl(d, (lane % RPL) * LPR, 64);
+    if (lane / RPL == j) mine = v;
+  }
+  if (lane < K) {
+    float* o = out + row * ldo + o_off + lane * 4;
+    o[0] = mine / scale;
+    o[1] = ox;
+    o[2] = oy;
+    o[3] = oz;
+  }
+}
+
+__global__ __launch_bounds__(256) void knn1_gather_kernel(const float* __restrict__ fvec, long long P, int C,
+                                                          const unsigned long long* __restrict__ keys, int n, int nseg, int frame,
+                                                          float* __restrict__ feat_out, int* __restrict__ idx_out) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n) return;
+  unsigned long long key = lane < nseg ? keys[(long long)q * nseg + lane] : KEY_MAX;
+  key = wave_min_u64(key);
+  unsigned idx = (unsigned)key;
+  if ((long long)idx >= P) idx = (unsigned)(P - 1);
+  if (idx_out && lane == 0) idx_out[q] = (int)idx;
+  const float* src = fvec + ((long long)frame * P + idx) * C;
+  for (int c = lane * 4; c < C; c += 256)
+    *reinterpret_cast<f32x4*>(feat_out + (long long)q * C + c) = *reinterpret_cast<const f32x4*>(src + c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Secondary operator: (2r+1)^2 bilinear window correlation, one wave per (frame, track).
+// All window samples share one fractional offset, so the wave first dots the (2r+2)^2 texel
+// patch with the target (two texel rows per 1-KiB load, half-wave shuffle reduction, results
+// staged in LDS) and then blends four neighbouring dots per output.
+template <int LPR>
+__global__ __launch_bounds__(256) void window_corr_kernel(const float* __restrict__ fmap, const float* __restrict__ targets,
+                                                          const float* __restrict__ coords, float* __restrict__ out, int BS, int N,
+                                                          int h, int w, int level, int radius, int ldo, int o_off) {
+  constexpr int C = 4 * LPR;
+  constexpr int RPL = 64 / LPR;
+  __shared__ float dots[4][16 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wave;  // bs * N + n
+  if (row >= (long long)BS * N) return;
+  const long long bs = row / N;
+  const int side = 2 * radius + 2;
+  const float inv = 1.0f / (float)(1 << level);
+  const float cx = coords[row * 2] * inv, cy = coords[row * 2 + 1] * inv;
+  const float fx0 = floorf(cx), fy0 = floorf(cy);
+  const int x0 = (int)fx0 - radius, y0 = (int)fy0 - radius;
+  const float ax = cx - fx0, ay = cy - fy0;
+  const int sub = lane / LPR, cq = lane % LPR;
+  const f32x4 tg = *reinterpret_cast<const f32x4*>(targets + row * C + cq * 4);
+  const float* fb = fmap + bs * (long long)h * w * C + cq * 4;
+  const int ntex = side * side;
+  for (int t0 = 0; t0 < ntex; t0 += RPL) {
+    const int tt = t0 + sub;
+    const int ty = tt / side, tx = tt - ty * side;  // patch[ty][tx] = texel (x0 + tx, y0 + ty)
+    const int gx = x0 + tx, gy = y0 + ty;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (tt < ntex && (unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h)
+      v = *reinterpret_cast<const f32x4*>(fb + ((long long)gy * w + gx) * C);
+    float d = tg[0] * v[0];
+    d = fmaf(tg[1], v[1], d);
+    d = fmaf(tg[2], v[2], d);
+    d = fmaf(tg[3], v[3], d);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (cq == 0 && tt < ntex) dots[wave][ty * 16 + tx] = d;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int win = 2 * radius + 1;
+  const float scale = sqrtf((float)C);
+  for (int o = lane; o < win * win; o += 64) {
+    const int a = o / win, b = o - a * win;  // sample at (cx + a - r, cy + b - r): first index runs along x
+    const float d00 = dots[wave][b * 16 + a], d01 = dots[wave][b * 16 + a + 1];
+    const float d10 = dots[wave][(b + 1) * 16 + a], d11 = dots[wave][(b + 1) * 16 + a + 1];
+    const float v = (1.f - ay) * ((1.f - ax) * d00 + ax * d01) + ay * ((1.f - ax) * d10 + ax * d11);
+    out[row * ldo + o_off + o] = v / scale;
+  }
+}
+
+}  // namespace
+
+extern "C" int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step, int T,
+                            int K, int nseg, unsigned long long* keys, void* stream) {
+  MVT_REQUIRE(xyz && coords && keys && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0);
+  MVT_REQUIRE(K >= 1 && K <= 16 && nseg >= 1 && nseg * K <= 64 && P < (1LL << 31));
+  MVT_REQUIRE((P + nseg - 1) / nseg >= K && ((P + nseg - 1) / nseg) * (nseg - 1) + K <= P);  // every segment holds >= K points
+  constexpr int Q = 8;
+  const int qgroups = (N + Q - 1) / Q;
+  const long long ntask = (long long)qgroups * S * nseg;
+  hipLaunchKernelGGL((knn_scan_kernel<Q>), dim3((unsigned)mvt_cdiv(ntask, 4)), dim3(256), 0, mvt_stream(stream), xyz, P, coords, N, S,
+                     frame0, frame_step, T, K, nseg, keys, qgroups);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_corr_gather_dot(const float* xyz, const float* fvec, long long P, int C, const float* targets,
+                                   const float* coords, const unsigned long long* keys, int N, int S, int frame0, int frame_step,
+                                   int T, int K, int nseg, float* out, int ldo, int o_off, int* idx_out, void* stream) {
+  MVT_REQUIRE(xyz && fvec && targets && coords && keys && out && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T);
+  MVT_REQUIRE(K >= 1 && K <= 16 && nseg >= 1 && nseg * K <= 64 && P >= K && P < (1LL << 31) && frame_step >= 0);
+  MVT_REQUIRE(o_off >= 0 && ldo >= o_off + 4 * K);
+  const unsigned blocks = (unsigned)mvt_cdiv((long long)N * S, 4);
+#define LAUNCH(LPR)                                                                                                             \
+  hipLaunchKernelGGL((corr_gather_dot_kernel<LPR>), dim3(blocks), dim3(256), 0, mvt_stream(stream), xyz, fvec, P, targets, coords, \
+                     keys, N, S, frame0, frame_step, T, K, nseg, out, ldo, o_off, idx_out)
+  switch (C) {
+    case 32: LAUNCH(8); break;
+    case 64: LAUNCH(16); break;
+    case 128: LAUNCH(32); break;
+    case 256: LAUNCH(64); break;
+    default: return MVT_ERR_ARG;
+  }
+#undef LAUNCH
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_knn1_gather(const float* fvec, long long P, int C, const unsigned long long* keys, int n, int nseg, int frame,
+                               float* feat_out, int* idx_out, void* stream) {
+  MVT_REQUIRE(fvec && keys && feat_out && n > 0 && nseg >= 1 && nseg <= 64 && C > 0 && C % 4 == 0 && P > 0 && frame >= 0);
+  hipLaunchKernelGGL(knn1_gather_kernel, dim3((unsigned)mvt_cdiv(n, 4)), dim3(256), 0, mvt_stream(stream), fvec, P, C, keys, n, nseg,
+                     frame, feat_out, idx_out);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_window_corr(const float* fmap, const float* targets, const float* coords, float* out, int BS, int N, int C,
+                               int h, int w, int level, int radius, int ldo, int o_off, void* stream) {
+  MVT_REQUIRE(fmap && targets && coords && out && BS > 0 && N > 0 && h > 0 && w > 0 && level >= 0 && level < 8);
+  MVT_REQUIRE(radius >= 1 && radius <= 7 && o_off >= 0 && ldo >= o_off + (2 * radius + 1) * (2 * radius + 1));
+  const unsigned blocks = (unsigned)mvt_cdiv((long long)BS * N, 4);
+#define LAUNCH(LPR)                                                                                                             \
+  hipLaunchKernelGGL((window_corr_kernel<LPR>), dim3(blocks), dim3(256), 0, mvt_stream(stream), fmap, targets, coords, out, BS, N, h, \
+                     w, level, radius, ldo, o_off)
+  switch (C) {
+    case 32: LAUNCH(8); break;
+    case 64: LAUNCH(16); break;
+    case 128: LAUNCH(32); break;
+    case 256: LAUNCH(64); break;
+    default: return MVT_ERR_ARG;
+  }
+#undef LAUNCH
+  return mvt_launch_status();
+}

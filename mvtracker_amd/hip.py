@@ -1,0 +1,196 @@
+"""ctypes binding of libmvtracker_hip.so (C ABI in include/mvtracker_hip.h).
+
+The library is the product: there is NO eager / CPU fallback.  Importing this module loads the
+shared object and raises ``RuntimeError`` if it is missing (build it with
+``python -m mvtracker_amd.build``); every wrapper raises on a non-zero return code.  PyTorch only
+provides device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvtracker_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f"{LIB_PATH} not found: the HIP library is required (no fallback path exists). "
+        "Build it with `python -m mvtracker_amd.build`.")
+_lib = C.CDLL(LIB_PATH)
+
+P, I, LL, F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+# name -> argument types (all return int unless listed in _RET)
+SIGNATURES = {
+    "mvt_abi_version": [],
+    "mvt_build_arch": [],
+    "mvt_gemm": [P, I, P, I, P, P, I, P, I, I, I, I, I, P],
+    "mvt_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
+    "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
+    "mvt_instnorm_stats": [P, I, P, P, I, LL, I, P],
+    "mvt_instnorm_apply": [P, P, P, P, P, I, LL, I, P],
+    "mvt_resize_bilinear_ac": [P, P, I, I, I, I, I, I, I, I, P],
+    "mvt_invert_cameras": [P, P, P, P, I, P],
+    "mvt_depth_subsample": [P, P, I, I, I, I, I, P],
+    "mvt_avgpool2": [P, P, LL, I, I, I, P],
+    "mvt_unproject": [P, P, P, P, I, I, I, I, I, I, P],
+    "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P],
+    "mvt_corr_gather_dot": [P, P, LL, I, P, P, P, I, I, I, I, I, I, I, P, I, I, P, P],
+    "mvt_knn1_gather": [P, LL, I, P, I, I, I, P, P, P],
+    "mvt_window_corr": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "mvt_pos_embed": [P, I, I, I, I, P, P],
+    "mvt_token_assemble": [P, P, I, P, I, P, P, P, I, I, I, P, I, P],
+    "mvt_delta_split": [P, I, P, P, P, P, LL, I, P, P],
+    "mvt_rowdot": [P, I, P, P, P, LL, I, P],
+    "mvt_layernorm": [P, I, P, P, P, I, LL, I, F, P],
+    "mvt_attention": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, P],
+    "mvt_broadcast_rows": [P, P, I, I, I, I, P],
+}
+_RET = {"mvt_build_arch": C.c_char_p}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = header / library mismatch
+    _fn.argtypes = _args
+    _fn.restype = _RET.get(_name, C.c_int)
+
+ACT_NONE, ACT_RELU, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2, 3
+IN_SLABS = 64
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("libmvtracker_hip needs device tensors (got a CPU tensor); there is no CPU path")
+    return t.data_ptr()
+
+
+def require_device(t):
+    """The product path has no CPU implementation: refuse host tensors loudly."""
+    if not t.is_cuda:
+        raise HipError("the MI355X tracker needs device tensors (got a CPU tensor); there is no CPU path")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _call(name, *args):
+    rc = getattr(_lib, name)(*args)
+    if rc != 0:
+        raise HipError(f"{name} failed with code {rc}" + (" (arguments rejected)" if rc == 1 else " (HIP launch error)"))
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+def abi_version() -> int:
+    return _lib.mvt_abi_version()
+
+
+def build_arch() -> str:
+    return _lib.mvt_build_arch().decode()
+
+
+# ------------------------------------------------------------------ thin typed wrappers
+def gemm(A, lda, Wt, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NONE):
+    _call("mvt_gemm", _ptr(A), lda, _ptr(Wt), ldw, _ptr(bias), _ptr(R), ldr, _ptr(Cm), ldc, M, N, K, act, _stream())
+
+
+def conv2d(x, wt, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE):
+    _call("mvt_conv2d", _ptr(x), _ptr(wt), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act, _stream())
+
+
+def rgb_to_nhwc4(rgbs, out, V, T, H, W, t0, nt):
+    _call("mvt_rgb_to_nhwc4", _ptr(_f32c(rgbs)), _ptr(out), V, T, H, W, t0, nt, _stream())
+
+
+def resize_nearest(x, out, planes, Hi, Wi, Ho, Wo):
+    _call("mvt_resize_nearest", _ptr(_f32c(x)), _ptr(out), planes, Hi, Wi, Ho, Wo, _stream())
+
+
+def instnorm_stats(x, ldx, partial, mean_rstd, n, HW, Cc):
+    _call("mvt_instnorm_stats", _ptr(x), ldx, _ptr(partial), _ptr(mean_rstd), n, HW, Cc, _stream())
+
+
+def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc):
+    _call("mvt_instnorm_apply", _ptr(x), _ptr(mean_rstd), _ptr(skip), _ptr(skip_stats), _ptr(y), n, HW, Cc, _stream())
+
+
+def resize_bilinear_ac(src, dst, n, Hs, Ws, Cc, Hd, Wd, ldd, c_off):
+    _call("mvt_resize_bilinear_ac", _ptr(src), _ptr(dst), n, Hs, Ws, Cc, Hd, Wd, ldd, c_off, _stream())
+
+
+def invert_cameras(intrs, extrs, kinv, einv, n):
+    _call("mvt_invert_cameras", _ptr(_f32c(intrs)), _ptr(_f32c(extrs)), _ptr(kinv), _ptr(einv), n, _stream())
+
+
+def depth_subsample(depths, out, V, T, H, W, s):
+    _call("mvt_depth_subsample", _ptr(_f32c(depths)), _ptr(out), V, T, H, W, s, _stream())
+
+
+def avgpool2(x, out, n, h, w, Cc):
+    _call("mvt_avgpool2", _ptr(x), _ptr(out), n, h, w, Cc, _stream())
+
+
+def unproject(depth_s, kinv, einv, xyz, V, T, hs, ws, stride, level):
+    _call("mvt_unproject", _ptr(depth_s), _ptr(kinv), _ptr(einv), _ptr(xyz), V, T, hs, ws, stride, level, _stream())
+
+
+def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys):
+    _call("mvt_knn_scan", _ptr(xyz), Pn, _ptr(coords), N, S, frame0, frame_step, T, K, nseg, _ptr(keys), _stream())
+
+
+def corr_gather_dot(xyz, fvec, Pn, Cc, targets, coords, keys, N, S, frame0, frame_step, T, K, nseg, out, ldo, o_off,
+                    idx_out=None):
+    _call("mvt_corr_gather_dot", _ptr(xyz), _ptr(fvec), Pn, Cc, _ptr(targets), _ptr(coords), _ptr(keys), N, S, frame0,
+          frame_step, T, K, nseg, _ptr(out), ldo, o_off, _ptr(idx_out), _stream())
+
+
+def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):
+    _call("mvt_knn1_gather", _ptr(fvec), Pn, Cc, _ptr(keys), n, nseg, frame, _ptr(feat_out), _ptr(idx_out), _stream())
+
+
+def window_corr(fmap, targets, coords, out, BS, N, Cc, h, w, level, radius, ldo, o_off):
+    _call("mvt_window_corr", _ptr(fmap), _ptr(targets), _ptr(coords), _ptr(out), BS, N, Cc, h, w, level, radius, ldo, o_off,
+          _stream())
+
+
+def pos_embed(coords, N, S, D, dim_padded, pos):
+    _call("mvt_pos_embed", _ptr(coords), N, S, D, dim_padded, _ptr(pos), _stream())
+
+
+def token_assemble(coords, fcorr, Fc, ffeats, Cc, mask_vis, pos, time_embed, N, S, E, x, ldx):
+    _call("mvt_token_assemble", _ptr(coords), _ptr(fcorr), Fc, _ptr(ffeats), Cc, _ptr(mask_vis), _ptr(pos), _ptr(time_embed),
+          N, S, E, _ptr(x), ldx, _stream())
+
+
+def delta_split(delta, ldd, gw, gb, coords, dn, rows, Cc, nan_flag=None):
+    _call("mvt_delta_split", _ptr(delta), ldd, _ptr(gw), _ptr(gb), _ptr(coords), _ptr(dn), rows, Cc, _ptr(nan_flag), _stream())
+
+
+def rowdot(x, ldx, w, b, out, rows, Cc):
+    _call("mvt_rowdot", _ptr(x), ldx, _ptr(w), _ptr(b), _ptr(out), rows, Cc, _stream())
+
+
+def layernorm(x, ldx, w, b, y, ldy, rows, Cc, eps):
+    _call("mvt_layernorm", _ptr(x), ldx, _ptr(w), _ptr(b), _ptr(y), ldy, rows, Cc, eps, _stream())
+
+
+def attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
+    _call("mvt_attention", _ptr(q), ldq, q_gs, q_is, _ptr(k), _ptr(v), ldkv, k_gs, k_is, _ptr(o), ldo, groups, nq, nk, heads,
+          dh, _stream())
+
+
+def broadcast_rows(v, x, ld, n, S, Cc):
+    _call("mvt_broadcast_rows", _ptr(v), _ptr(x), ld, n, S, Cc, _stream())

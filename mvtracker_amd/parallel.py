@@ -1,0 +1,80 @@
+"""Multi-GPU execution of the tracking forward path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+Contract: the query set is partitioned into contiguous shards and every
+shard is an INDEPENDENT forward -- exactly what the reference does when it runs query subsets
+(evaluation_predictor_3dpt.py:191-277, demo.py:809-824); the 64 virtual tracks of the updater couple
+the tracks of one call, so a shard's result equals the reference run on that subset, not on the
+union.  The only data-path exchange happens once, before the refinement loop: the frames are split
+into contiguous blocks, each rank encodes its block and the level-0 feature maps are all-gathered
+(each rank then derives pyramid levels 1-3 and the point clouds locally).  No collective runs inside
+the refinement loop; the small outputs are all-gathered at the end when requested.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class ShardedTracker:
+    def __init__(self, model, group: Optional["dist.ProcessGroup"] = None):
+        self.model = model
+        self.group = group
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group), dist.get_rank(self.group)
+        return 1, 0
+
+    @staticmethod
+    def shard_bounds(n: int, world: int, rank: int):
+        per = (n + world - 1) // world
+        return min(n, rank * per), min(n, (rank + 1) * per)
+
+    def _all_gather(self, local: torch.Tensor, world: int) -> torch.Tensor:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        else:
+            parts = list(out.chunk(world, dim=0))
+            dist.all_gather(parts, local.contiguous(), group=self.group)
+        return out
+
+    @torch.no_grad()
+    def __call__(self, rgbs, depths, query_points, intrs, extrs, iters=4, gather_output=True):
+        world, rank = self._world()
+        m = self.model
+        if world == 1:
+            return m(rgbs, depths, query_points, intrs, extrs, iters=iters)
+        _, V, T, _, H, W = rgbs.shape
+        N = query_points.shape[1]
+        a, b = self.shard_bounds(N, world, rank)
+        assert b > a, "fewer queries than ranks"
+        t0 = int(query_points[0, :, 0].long().min().item())  # global first frame: identical on every rank
+        store = None
+        if t0 < T - m.S // 2:
+            f32 = lambda t: t.to(torch.float32).contiguous()
+            r0, d0, i0, e0 = f32(rgbs[0]), f32(depths[0]), f32(intrs[0]), f32(extrs[0])
+            cnt = (T - t0 + world - 1) // world  # frames per rank (last ranks may get fewer / none)
+            lo, hi = min(T, t0 + rank * cnt), min(T, t0 + (rank + 1) * cnt)
+            hs, ws, C = H // m.stride, W // m.stride, m.latent_dim
+            local = torch.zeros(cnt, V, hs, ws, C, device=rgbs.device)
+            if hi > lo:
+                local[:hi - lo] = m.encode_frames(r0, t0=lo, t1=hi)[lo:hi]
+            gathered = self._all_gather(local, world)  # frames t0 .. t0 + world*cnt - 1
+            level0 = torch.zeros(T, V, hs, ws, C, device=rgbs.device)
+            level0[t0:] = gathered[:T - t0]
+            store = m.build_frame_store(r0, d0, i0, e0, t0=t0, level0=level0)
+        res = m(rgbs, depths, query_points[:, a:b], intrs, extrs, iters=iters, frame_store=store)
+        if not gather_output:
+            return res
+        per = (N + world - 1) // world
+        traj = torch.zeros(per, T, 3, device=rgbs.device)
+        vis = torch.zeros(per, T, device=rgbs.device)
+        traj[:b - a] = res["traj_e"][0].permute(1, 0, 2)
+        vis[:b - a] = res["vis_e"][0].t()
+        traj = self._all_gather(traj, world)[:N].permute(1, 0, 2)[None]
+        vis = self._all_gather(vis, world)[:N].t()[None]
+        return {"traj_e": traj, "vis_e": vis, "feat_init": res["feat_init"]}

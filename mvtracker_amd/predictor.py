@@ -1,0 +1,185 @@
+"""EvaluationPredictor on MI355X: the drop-in boundary of the tracking forward path.
+
+Mirrors ``mvtracker.models.evaluation_predictor_3dpt.EvaluationPredictor`` (reference
+evaluation_predictor_3dpt.py:17-414): same constructor, same ``forward`` keyword arguments
+(``rgbs, depths, query_points_3d, intrs, extrs`` + ignored ``**kwargs``), same result dict
+(``traj_e``, ``vis_e`` bool, ``vis_e_as_prob``), so ``demo.py`` and ``Evaluator.evaluate_sequence``
+can drive it unchanged.  The heavy lifting is ``self.model`` (mvtracker_amd.tracker.MVTracker);
+the resize runs in the HIP library, the support-grid synthesis is a few hundred points of
+bookkeeping on device tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+
+
+def _bilinear_sample_depth(depth: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Four clamped taps with weights from the unclamped corners (reference model_utils.py:81-165).
+
+    depth (H,W), x,y (M,) pixel coordinates -> (M,)."""
+    H, W = depth.shape
+    x0, y0 = torch.floor(x), torch.floor(y)
+    x1, y1 = x0 + 1, y0 + 1
+    cx0, cx1 = x0.clamp(0, W - 1).long(), x1.clamp(0, W - 1).long()
+    cy0, cy1 = y0.clamp(0, H - 1).long(), y1.clamp(0, H - 1).long()
+    flat = depth.reshape(-1)
+    return ((x1 - x) * (y1 - y) * flat[cy0 * W + cx0] + (x - x0) * (y1 - y) * flat[cy0 * W + cx1]
+            + (x1 - x) * (y - y0) * flat[cy1 * W + cx0] + (x - x0) * (y - y0) * flat[cy1 * W + cx1])
+
+
+def points_on_a_grid(size: int, extent: Tuple[float, float], center=None, device="cpu") -> torch.Tensor:
+    """(size*size, 2) pixel (x, y) grid with margin W/64 (reference model_utils.py:361-417)."""
+    if size == 1:
+        return torch.tensor([[extent[1] / 2, extent[0] / 2]], device=device)
+    if center is None:
+        center = [extent[0] / 2, extent[1] / 2]
+    m = extent[1] / 64
+    ys = torch.linspace(m - extent[0] / 2 + center[0], extent[0] / 2 + center[0] - m, size, device=device)
+    xs = torch.linspace(m - extent[1] / 2 + center[1], extent[1] / 2 + center[1] - m, size, device=device)
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    return torch.stack([gx, gy], dim=-1).reshape(-1, 2)
+
+
+class EvaluationPredictor(torch.nn.Module):
+    def __init__(
+            self,
+            multiview_model: torch.nn.Module,
+            interp_shape: Optional[Tuple[int, int]] = (384, 512),
+            visibility_threshold=0.5,
+            grid_size: int = 5,
+            n_grids_per_view: int = 1,
+            local_grid_size: int = 8,
+            local_extent: int = 50,
+            single_point: bool = False,
+            sift_size: int = 0,
+            num_uniformly_sampled_pts: int = 0,
+            n_iters: int = 6,
+    ) -> None:
+        super().__init__()
+        self.model = multiview_model
+        self.interp_shape = interp_shape
+        self.visibility_threshold = visibility_threshold
+        self.grid_size = grid_size
+        self.n_grids_per_view = n_grids_per_view
+        self.local_grid_size = local_grid_size
+        self.local_extent = local_extent
+        self.single_point = single_point
+        self.sift_size = sift_size
+        self.num_uniformly_sampled_pts = num_uniformly_sampled_pts
+        self.n_iters = n_iters
+        self.model.eval()
+
+    # ---- helpers -------------------------------------------------------------------------
+    @staticmethod
+    def _invert(intrs, extrs):
+        """K^-1 (V,T,3,3) and rows 0..2 of [R|t]^-1 (V,T,3,4) through the library (fp64 closed form)."""
+        V, T = intrs.shape[:2]
+        kinv = torch.empty(V * T, 9, device=intrs.device)
+        einv = torch.empty(V * T, 12, device=intrs.device)
+        hip.invert_cameras(intrs.reshape(V * T, 9).contiguous(), extrs.reshape(V * T, 12).contiguous(), kinv, einv, V * T)
+        return kinv.reshape(V, T, 3, 3), einv.reshape(V, T, 3, 4)
+
+    @staticmethod
+    def _unproject(pix, z, kinv, einv):
+        ph = torch.cat([pix, torch.ones_like(pix[:, :1])], 1)
+        cam = (ph @ kinv.t()) * z[:, None]
+        return cam @ einv[:, :3].t() + einv[:, 3]
+
+    def _support_rows(self, depth, pix, kinv, einv, t):
+        z = _bilinear_sample_depth(depth, pix[:, 0], pix[:, 1])
+        world = self._unproject(pix, z, kinv, einv)
+        return torch.cat([torch.full_like(world[:, :1], float(t)), world], 1)
+
+    # ---- forward ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(
+            self,
+            rgbs,
+            depths,
+            query_points_3d,
+            intrs,
+            extrs,
+            save_debug_logs=False,
+            debug_logs_path="",
+            query_points_view=None,
+            **kwargs,
+    ):
+        batch_size, num_views, num_frames, _, height_raw, width_raw = rgbs.shape
+        _, num_points, _ = query_points_3d.shape
+        assert rgbs.shape == (batch_size, num_views, num_frames, 3, height_raw, width_raw)
+        assert depths.shape == (batch_size, num_views, num_frames, 1, height_raw, width_raw)
+        assert query_points_3d.shape == (batch_size, num_points, 4)
+        assert intrs.shape == (batch_size, num_views, num_frames, 3, 3)
+        assert extrs.shape == (batch_size, num_views, num_frames, 3, 4)
+        if batch_size != 1:
+            raise NotImplementedError
+        if self.sift_size > 0:
+            raise NotImplementedError
+        if self.num_uniformly_sampled_pts > 0:
+            raise NotImplementedError("uniformly sampled support points draw from the global RNG upstream; not supported")
+        hip.require_device(rgbs)
+        dev = rgbs.device
+        V, T = num_views, num_frames
+        rgbs = rgbs.to(torch.float32).contiguous()
+        depths = depths.to(torch.float32).contiguous()
+        intrs = intrs.to(torch.float32)
+        extrs = extrs.to(torch.float32)
+        query_points_3d = query_points_3d.to(torch.float32)
+
+        if self.interp_shape is None:  # evaluation_predictor_3dpt.py:72-87
+            height, width = height_raw, width_raw
+        else:
+            height, width = self.interp_shape
+            r = torch.empty(1, V, T, 3, height, width, device=dev)
+            hip.resize_nearest(rgbs, r, V * T * 3, height_raw, width_raw, height, width)
+            d = torch.empty(1, V, T, 1, height, width, device=dev)
+            hip.resize_nearest(depths, d, V * T, height_raw, width_raw, height, width)
+            rgbs, depths = r, d
+            rs = torch.tensor([[width / width_raw, 0, 0], [0, height / height_raw, 0], [0, 0, 1]], device=dev,
+                              dtype=intrs.dtype)
+            intrs = torch.einsum("ij,BVTjk->BVTik", rs, intrs)
+
+        kinv, einv = self._invert(intrs[0], extrs[0])
+        support = torch.zeros(0, 4, device=dev)
+        if self.grid_size > 0:  # :101-120
+            pix = points_on_a_grid(self.grid_size, (height, width), device=dev)
+            rows = []
+            for t in range(0, T, max(1, T // self.n_grids_per_view)):
+                for v in range(V):
+                    rows.append(self._support_rows(depths[0, v, t, 0], pix, kinv[v, t], einv[v, t], t))
+            support = torch.cat(rows, 0)
+
+        fwd = dict(intrs=intrs, extrs=extrs, iters=self.n_iters, save_debug_logs=save_debug_logs,
+                   debug_logs_path=debug_logs_path, query_points_view=query_points_view, **kwargs)
+        if self.single_point:  # :191-339, one forward per query with its local grids
+            traj_e = torch.zeros(1, T, num_points, 3, device=dev)
+            vis_e = torch.zeros(1, T, num_points, device=dev)
+            qt = query_points_3d[0, :, 0].long().cpu().tolist()
+            qh = torch.cat([query_points_3d[0, :, 1:], torch.ones(num_points, 1, device=dev)], 1)
+            for i in range(num_points):
+                t = qt[i]
+                rows = []
+                if self.local_grid_size > 0:
+                    for v in range(V):
+                        cam = extrs[0, v, t] @ qh[i]
+                        ph = intrs[0, v, t] @ cam
+                        px, py = (ph[0] / ph[2]).item(), (ph[1] / ph[2]).item()
+                        pix = points_on_a_grid(self.local_grid_size, (self.local_extent, self.local_extent), (py, px), dev)
+                        ok = (pix[:, 0] >= 0) & (pix[:, 0] < width) & (pix[:, 1] >= 0) & (pix[:, 1] < height)
+                        if not bool(ok.any()):
+                            continue
+                        rows.append(self._support_rows(depths[0, v, t, 0], pix[ok], kinv[v, t], einv[v, t], t))
+                q_i = torch.cat([query_points_3d[0, i:i + 1]] + rows + [support], 0)[None]
+                res = self.model(rgbs, depths=depths, query_points=q_i, **fwd)
+                traj_e[:, :, i] = res["traj_e"][:, :, 0]
+                vis_e[:, :, i] = res["vis_e"][:, :, 0]
+        else:  # joint mode, :341-360
+            q = torch.cat([query_points_3d[0], support], 0)[None]
+            res = self.model(rgbs, depths=depths, query_points=q, **fwd)
+            traj_e = res["traj_e"][:, :, :num_points, :]
+            vis_e = res["vis_e"][:, :, :num_points]
+        return {"traj_e": traj_e, "vis_e": vis_e > self.visibility_threshold, "vis_e_as_prob": vis_e}

@@ -111,7 +111,7 @@ def make_clip(seed: int, V: int, T: int, H: int, W: int, N: int, late_queries: b
             "extrs": extrs[None].astype(np.float32), "query_points": q[None].astype(np.float32)}
 
 
-def weight_for_key(key: str, shape: Tuple[int, ...], seed: int = 0, delta_scale: float = 0.05) -> np.ndarray:
+def weight_for_key(key: str, shape: Tuple[int, ...], seed: int = 0, delta_scale: float = 0.005) -> np.ndarray:
     """One tensor of the seeded weights recipe, float32."""
     rng = np.random.default_rng((zlib.crc32(key.encode()) ^ seed) & 0xFFFFFFFF)
     if key.endswith("virual_tracks"):
@@ -129,6 +129,6 @@ def weight_for_key(key: str, shape: Tuple[int, ...], seed: int = 0, delta_scale:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def make_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, delta_scale: float = 0.05):
+def make_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, delta_scale: float = 0.005):
     """key -> float32 ndarray for every entry of ``shapes``."""
     return {k: weight_for_key(k, tuple(s), seed, delta_scale) for k, s in sorted(shapes.items())}

@@ -1,0 +1,582 @@
+"""MVTracker on MI355X: host-side mirror of the reference model's interface.
+
+Same constructor kwargs, ``forward`` signature, result dict and ``state_dict`` keys as
+``mvtracker.models.core.mvtracker.mvtracker.MVTracker`` (reference mvtracker.py:93-181, 412-732),
+so a Hydra ``_target_`` or a checkpoint can be pointed at this class unchanged.  All arithmetic
+runs in libmvtracker_hip.so (see include/mvtracker_hip.h); this file only sequences kernel
+launches, owns device buffers and does the per-window bookkeeping on tiny tensors.
+
+Differences from the reference, all result-preserving:
+  * every frame is encoded exactly once up front into a frame-major, channels-last "frame store"
+    (features + world-space points for the 4 pyramid levels); windows are slices of it, the
+    reference's repeat-last-frame padding is a clamped frame index inside the kernels;
+  * track state is track-major ([N][S][.]) so the token / delta layouts need no permutes;
+  * one host sync per call (the query frame indices), none inside the refinement loop; the NaN
+    guard (reference mvtracker.py:401-404) is a device flag read once at the end.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip
+
+log = logging.getLogger(__name__)
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted state_dict keys."""
+
+
+def _insert(root: nn.Module, dotted: str, tensor: torch.Tensor) -> None:
+    *path, leaf = dotted.split(".")
+    m = root
+    for p in path:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    m.register_parameter(leaf, nn.Parameter(tensor, requires_grad=False))
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class MVTracker(nn.Module):
+    def __init__(
+            self,
+            sliding_window_len=12,
+            stride=4,
+            normalize_scene_in_fwd_pass=False,
+            fmaps_dim=128,
+            add_space_attn=True,
+            num_heads=6,
+            hidden_size=384,
+            space_depth=6,
+            time_depth=6,
+            num_virtual_tracks=64,
+            use_flash_attention=True,
+            corr_n_groups=1,
+            corr_n_levels=4,
+            corr_neighbors=16,
+            corr_add_neighbor_offset=True,
+            corr_add_neighbor_xyz=False,
+            corr_filter_invalid_depth=False,
+    ):
+        super().__init__()
+        if normalize_scene_in_fwd_pass:
+            raise NotImplementedError("normalize_scene_in_fwd_pass is broken upstream (mvtracker.py:463-477)")
+        if corr_filter_invalid_depth:
+            raise NotImplementedError("corr_filter_invalid_depth=True gathers with mismatched indices upstream "
+                                      "(mvtracker.py:820-829); only the default False is implemented")
+        if corr_n_groups != 1 or not corr_add_neighbor_offset or corr_add_neighbor_xyz:
+            raise NotImplementedError("only the shipped correlation layout (1 group, neighbour offsets) is implemented")
+        if not add_space_attn or time_depth != space_depth:
+            raise NotImplementedError("only add_space_attn=True with time_depth == space_depth is implemented")
+        if fmaps_dim not in (32, 64, 128, 256) or not (1 <= corr_neighbors <= 16) or stride != 4:
+            raise NotImplementedError("fmaps_dim in {32,64,128,256}, corr_neighbors <= 16, stride 4")
+        self.S = sliding_window_len
+        self.stride = stride
+        self.latent_dim = fmaps_dim
+        self.flow_embed_dim = 64
+        self.corr_n_levels = corr_n_levels
+        self.corr_neighbors = corr_neighbors
+        self.num_heads = num_heads
+        self.dim_head = 48
+        self.hidden = hidden_size
+        self.depth = time_depth
+        self.nv = num_virtual_tracks
+        self.use_flash_attention = use_flash_attention  # accepted for config compatibility; same math
+        self.updateformer_input_dim = (self.flow_embed_dim + 1) * 3 + corr_neighbors * corr_n_levels * 4 + fmaps_dim + 2
+        self.out_dim = 3 + fmaps_dim
+        for key, shape in self._shapes().items():
+            _insert(self, key, self._init_tensor(key, shape))
+        self._packed: Optional[dict] = None
+        self._packed_sig = None
+        d = self.updateformer_input_dim
+        self._time_embed_host = self._make_time_embed(self.S, d)
+
+    # ------------------------------------------------------------------ parameters
+    def _shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """state_dict contract."""
+        s: Dict[str, Tuple[int, ...]] = {}
+
+        def wb(name, *shape):
+            s[name + ".weight"] = tuple(shape)
+            s[name + ".bias"] = (shape[0],)
+
+        wb("fnet.conv1", 64, 3, 7, 7)
+        cin = 64
+        for li, cout in ((1, 64), (2, 96), (3, 128), (4, 128)):
+            wb(f"fnet.layer{li}.0.conv1", cout, cin, 3, 3)
+            wb(f"fnet.layer{li}.0.conv2", cout, cout, 3, 3)
+            if li != 1:
+                wb(f"fnet.layer{li}.0.downsample.0", cout, cin, 1, 1)
+            wb(f"fnet.layer{li}.1.conv1", cout, cout, 3, 3)
+            wb(f"fnet.layer{li}.1.conv2", cout, cout, 3, 3)
+            cin = cout
+        wb("fnet.conv2", self.latent_dim * 2, 416, 3, 3)
+        wb("fnet.conv3", self.latent_dim, self.latent_dim * 2, 1, 1)
+        h, inner, mlp = self.hidden, self.num_heads * self.dim_head, int(self.hidden * 4.0)
+        u = "updateformer."
+        s[u + "virual_tracks"] = (1, self.nv, 1, h)
+        wb(u + "input_transform", h, self.updateformer_input_dim)
+        wb(u + "flow_head.0", self.out_dim, h)
+        wb(u + "flow_head.2", self.out_dim, self.out_dim)
+        wb(u + "flow_head.4", self.out_dim, self.out_dim)
+        for i in range(self.depth):
+            for blk, attn in (("time_blocks", "attn"), ("space_virtual_blocks", "attn"),
+                              ("space_point2virtual_blocks", "cross_attn"), ("space_virtual2point_blocks", "cross_attn")):
+                p = f"{u}{blk}.{i}"
+                if attn == "cross_attn":
+                    s[p + ".norm_context.weight"] = (h,)
+                    s[p + ".norm_context.bias"] = (h,)
+                wb(f"{p}.{attn}.to_q", inner, h)
+                wb(f"{p}.{attn}.to_kv", 2 * inner, h)
+                wb(f"{p}.{attn}.to_out", h, inner)
+                wb(p + ".mlp.fc1", mlp, h)
+                wb(p + ".mlp.fc2", h, mlp)
+        s["ffeats_norm.weight"] = (self.latent_dim,)
+        s["ffeats_norm.bias"] = (self.latent_dim,)
+        wb("ffeats_updater.0", self.latent_dim, self.latent_dim)
+        wb("vis_predictor.0", 1, self.latent_dim)
+        return s
+
+    @staticmethod
+    def _init_tensor(key: str, shape) -> torch.Tensor:
+        t = torch.zeros(shape)
+        if key.endswith("virual_tracks"):
+            return torch.randn(shape)
+        if key.endswith(".bias"):
+            return t
+        if "norm" in key.split(".")[-2]:
+            return torch.ones(shape)
+        if key.startswith("fnet."):
+            nn.init.kaiming_normal_(t, mode="fan_out", nonlinearity="relu")
+        elif "flow_head" in key:
+            nn.init.trunc_normal_(t, std=0.001)
+        else:
+            nn.init.xavier_uniform_(t)
+        return t
+
+    @staticmethod
+    def _make_time_embed(S: int, D: int) -> torch.Tensor:
+        """1-D sin|cos embedding of s/S, fp64 on the host, first D of D+D%2 columns (mvtracker.py:333-344)."""
+        dim = D + (D % 2)
+        omega = np.arange(dim // 2, dtype=np.float64)
+        omega /= dim / 2.0
+        omega = 1.0 / 10000 ** omega
+        pos = (torch.linspace(0, S - 1, S).reshape(S, 1) / S).numpy().reshape(-1)
+        out = np.einsum("m,d->md", pos, omega)
+        return torch.from_numpy(np.concatenate([np.sin(out), np.cos(out)], axis=1)).float()[:, :D].contiguous()
+
+    def init_stats(self):  # reference API (mvtracker.py:190-242); statistics are not collected here
+        pass
+
+    def consume_stats(self):
+        pass
+
+    # ------------------------------------------------------------------ weight packing for the kernels
+    def _signature(self, dev):
+        return (str(dev),) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def _pack(self, dev) -> dict:
+        sig = self._signature(dev)
+        if self._packed is not None and self._packed_sig == sig:
+            return self._packed
+        sd = {k: v.detach().to(device=dev, dtype=torch.float32) for k, v in self.state_dict().items()}
+        pk: dict = {}
+
+        def conv(name):
+            w = sd[name + ".weight"]
+            pk[name] = (w.permute(0, 2, 3, 1).contiguous(), sd[name + ".bias"].contiguous())
+
+        def lin(name, w=None, b=None):
+            w = sd[name + ".weight"] if w is None else w
+            b = sd[name + ".bias"] if b is None else b
+            n, k = w.shape
+            wp = torch.zeros(n, _round_up(k, 32), device=dev)
+            wp[:, :k] = w
+            pk[name] = (wp, b.contiguous(), n, k)
+
+        w = sd["fnet.conv1.weight"]  # (64,3,7,7) -> [64][7][32] with element kw*4+c
+        st = torch.zeros(64, 7, 8, 4, device=dev)
+        st[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        pk["fnet.conv1"] = (st.reshape(64, 7 * 32).contiguous(), sd["fnet.conv1.bias"].contiguous())
+        for k in sd:
+            if k.startswith("fnet.") and k.endswith(".weight") and k != "fnet.conv1.weight":
+                conv(k[:-7])
+        u = "updateformer."
+        for name in ("input_transform", "flow_head.0", "flow_head.2", "flow_head.4"):
+            lin(u + name)
+        for i in range(self.depth):
+            for blk in ("time_blocks", "space_virtual_blocks"):
+                p = f"{u}{blk}.{i}"
+                lin(p + ".attn.qkv", torch.cat([sd[p + ".attn.to_q.weight"], sd[p + ".attn.to_kv.weight"]], 0),
+                    torch.cat([sd[p + ".attn.to_q.bias"], sd[p + ".attn.to_kv.bias"]], 0))
+                lin(p + ".attn.to_out")
+                lin(p + ".mlp.fc1")
+                lin(p + ".mlp.fc2")
+            for blk in ("space_point2virtual_blocks", "space_virtual2point_blocks"):
+                p = f"{u}{blk}.{i}"
+                pk[p + ".norm_context"] = (sd[p + ".norm_context.weight"].contiguous(), sd[p + ".norm_context.bias"].contiguous())
+                for nme in (".cross_attn.to_q", ".cross_attn.to_kv", ".cross_attn.to_out", ".mlp.fc1", ".mlp.fc2"):
+                    lin(p + nme)
+        pk["virtual"] = sd[u + "virual_tracks"].reshape(self.nv, self.hidden).contiguous()
+        pk["ffeats_norm"] = (sd["ffeats_norm.weight"].contiguous(), sd["ffeats_norm.bias"].contiguous())
+        lin("ffeats_updater.0")
+        pk["vis"] = (sd["vis_predictor.0.weight"].reshape(-1).contiguous(), sd["vis_predictor.0.bias"].contiguous())
+        pk["time_embed"] = self._time_embed_host.to(dev)
+        self._packed, self._packed_sig = pk, sig
+        return pk
+
+    # ------------------------------------------------------------------ encoder (reference spatracker/blocks.py:214-284)
+    def _conv(self, pk, name, x, n, H, W, cin, cout, k, stride, pad, out=None, ldo=None):
+        wt, b = pk[name]
+        Ho = (H + 2 * pad - k) // stride + 1
+        Wo = (W + 2 * pad - k) // stride + 1
+        if out is None:
+            out = torch.empty(n, Ho, Wo, cout, device=x.device)
+            ldo = cout
+        hip.conv2d(x, wt, b, out, n, H, W, cin, cout, k, k, stride, pad, ldo)
+        return out, Ho, Wo
+
+    def _inorm(self, x, n, HW, C, skip=None, skip_stats=None, apply=True):
+        partial = torch.empty(n * hip.IN_SLABS * C * 2, device=x.device, dtype=torch.float64)
+        st = torch.empty(n, C, 2, device=x.device)
+        hip.instnorm_stats(x, C, partial, st, n, HW, C)
+        if apply:
+            hip.instnorm_apply(x, st, skip, skip_stats, x, n, HW, C)
+        return st
+
+    def _res_block(self, pk, p, x, n, H, W, cin, cout, stride):
+        y, Ho, Wo = self._conv(pk, p + ".conv1", x, n, H, W, cin, cout, 3, stride, 1)
+        self._inorm(y, n, Ho * Wo, cout)
+        y2, _, _ = self._conv(pk, p + ".conv2", y, n, Ho, Wo, cout, cout, 3, 1, 1)
+        if (p + ".downsample.0") in pk:
+            d, _, _ = self._conv(pk, p + ".downsample.0", x, n, H, W, cin, cout, 1, stride, 0)
+            dst = self._inorm(d, n, Ho * Wo, cout, apply=False)
+            self._inorm(y2, n, Ho * Wo, cout, skip=d, skip_stats=dst)
+        else:
+            self._inorm(y2, n, Ho * Wo, cout, skip=x)
+        return y2, Ho, Wo
+
+    def _encode(self, pk, x4, n, H, W, out_rows):
+        """x4 (n,H,W,4) normalised RGB -> writes (n, H/4, W/4, C) into ``out_rows``."""
+        C = self.latent_dim
+        hs, ws = H // self.stride, W // self.stride
+        x, h, w = self._conv(pk, "fnet.conv1", x4, n, H, W, 4, 64, 7, 2, 3)
+        self._inorm(x, n, h * w, 64)
+        cat = torch.empty(n, hs, ws, 416, device=x4.device)
+        cin, off = 64, 0
+        for li, (cout, stride) in enumerate(((64, 1), (96, 2), (128, 2), (128, 2)), start=1):
+            x, h, w = self._res_block(pk, f"fnet.layer{li}.0", x, n, h, w, cin, cout, stride)
+            x, h, w = self._res_block(pk, f"fnet.layer{li}.1", x, n, h, w, cout, cout, 1)
+            hip.resize_bilinear_ac(x, cat, n, h, w, cout, hs, ws, 416, off)
+            cin, off = cout, off + cout
+        y, _, _ = self._conv(pk, "fnet.conv2", cat, n, hs, ws, 416, 2 * C, 3, 1, 1)
+        self._inorm(y, n, hs * ws, 2 * C)
+        self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C)
+
+    def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16):
+        """rgbs (V,T,3,H,W) in [0,255] -> level-0 features (T,V,H/4,W/4,C); frames outside [t0,t1) are left zero."""
+        V, T, _, H, W = rgbs.shape
+        t1 = T if t1 is None else t1
+        pk = self._pack(rgbs.device)
+        hs, ws = H // self.stride, W // self.stride
+        F0 = torch.zeros(T, V, hs, ws, self.latent_dim, device=rgbs.device)
+        step = max(1, images_per_chunk // V)
+        for a in range(t0, t1, step):
+            nt = min(step, t1 - a)
+            x4 = torch.empty(nt * V, H, W, 4, device=rgbs.device)
+            hip.rgb_to_nhwc4(rgbs, x4, V, T, H, W, a, nt)
+            self._encode(pk, x4, nt * V, H, W, F0[a:a + nt])
+        return F0
+
+    # ------------------------------------------------------------------ frame store (model_utils.py:420-482)
+    def build_frame_store(self, rgbs, depths, intrs, extrs, t0=0, level0=None):
+        """Features and world-space points of every pyramid level, frame-major.
+
+        rgbs (V,T,3,H,W), depths (V,T,1,H,W), intrs (V,T,3,3), extrs (V,T,3,4).  ``level0`` (T,V,H/4,W/4,C)
+        may carry level-0 features encoded elsewhere (frames split across GPUs, mvtracker_amd.parallel)."""
+        V, T, _, H, W = rgbs.shape
+        dev = rgbs.device
+        hs, ws = H // self.stride, W // self.stride
+        C = self.latent_dim
+        fv = [self.encode_frames(rgbs, t0) if level0 is None else level0]
+        for lvl in range(1, self.corr_n_levels):
+            h, w = hs >> (lvl - 1), ws >> (lvl - 1)
+            nxt = torch.zeros(T, V, h // 2, w // 2, C, device=dev)
+            hip.avgpool2(fv[-1][t0:], nxt[t0:], (T - t0) * V, h, w, C)
+            fv.append(nxt)
+        kinv = torch.empty(V * T, 9, device=dev)
+        einv = torch.empty(V * T, 12, device=dev)
+        hip.invert_cameras(intrs.reshape(V * T, 9), extrs.reshape(V * T, 12), kinv, einv, V * T)
+        ds = torch.empty(T, V, hs, ws, device=dev)
+        hip.depth_subsample(depths.reshape(V, T, H, W), ds, V, T, H, W, self.stride)
+        xyz = []
+        for lvl in range(self.corr_n_levels):
+            o = torch.empty(T, V, hs >> lvl, ws >> lvl, 4, device=dev)
+            hip.unproject(ds, kinv, einv, o, V, T, hs, ws, self.stride, lvl)
+            xyz.append(o)
+        P = [V * (hs >> lvl) * (ws >> lvl) for lvl in range(self.corr_n_levels)]
+        return {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds}
+
+    def _nseg(self, P: int, K: int) -> int:
+        n = max(1, min(64 // K, P // 8192, 4))
+        while n > 1 and ((P + n - 1) // n) * (n - 1) + K > P:
+            n -= 1
+        return n
+
+    # ------------------------------------------------------------------ updater (cotracker2/blocks.py:455-494)
+    def _lin(self, pk, name, A, lda, M, out, ldc, act=hip.ACT_NONE, R=None, ldr=0):
+        wp, b, n, k = pk[name]
+        hip.gemm(A, lda, wp, wp.shape[1], b, R, ldr, out, ldc, M, n, k, act)
+
+    def _mlp_residual(self, pk, p, tok, rows, xn, hbuf):
+        h = self.hidden
+        hip.layernorm(tok, h, None, None, xn, h, rows, h, 1e-6)
+        self._lin(pk, p + ".mlp.fc1", xn, h, rows, hbuf, 4 * h, hip.ACT_GELU_TANH)
+        self._lin(pk, p + ".mlp.fc2", hbuf, 4 * h, rows, tok, h, R=tok, ldr=h)
+
+    def _update_former(self, pk, x, ldx, n, delta, ldd):
+        S, h, nv, H, dh = self.S, self.hidden, self.nv, self.num_heads, self.dim_head
+        inner = H * dh
+        dev = x.device
+        Mp, Mv = n * S, nv * S
+        M = Mp + Mv
+        tok = torch.empty(M, h, device=dev)
+        xn = torch.empty(M, h, device=dev)
+        ctx = torch.empty(M, h, device=dev)
+        qkv = torch.empty(M, 3 * inner, device=dev)
+        att = torch.empty(M, inner, device=dev)
+        hbuf = torch.empty(M, 4 * h, device=dev)
+        u = "updateformer."
+        self._lin(pk, u + "input_transform", x, ldx, Mp, tok, h)
+        hip.broadcast_rows(pk["virtual"], tok[Mp:], h, nv, S, h)
+        pt, vt = tok[:Mp], tok[Mp:]
+        for i in range(self.depth):
+            # time attention over the S frames of every (point or virtual) track
+            p = f"{u}time_blocks.{i}"
+            hip.layernorm(tok, h, None, None, xn, h, M, h, 1e-6)
+            self._lin(pk, p + ".attn.qkv", xn, h, M, qkv, 3 * inner)
+            hip.attention(qkv, 3 * inner, S, 1, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, S, 1, att, inner, n + nv, S, S, H, dh)
+            self._lin(pk, p + ".attn.to_out", att, inner, M, tok, h, R=tok, ldr=h)
+            self._mlp_residual(pk, p, tok, M, xn, hbuf)
+            # virtual <- point cross attention, per frame (row of item j in frame t is j*S + t)
+            p = f"{u}space_virtual2point_blocks.{i}"
+            hip.layernorm(vt, h, None, None, xn[Mp:], h, Mv, h, 1e-6)
+            hip.layernorm(pt, h, *pk[p + ".norm_context"], ctx[:Mp], h, Mp, h, 1e-5)
+            self._lin(pk, p + ".cross_attn.to_q", xn[Mp:], h, Mv, qkv[Mp:], 3 * inner)
+            self._lin(pk, p + ".cross_attn.to_kv", ctx[:Mp], h, Mp, qkv[:Mp, inner:], 3 * inner)
+            hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, n, H,
+                          dh)
+            self._lin(pk, p + ".cross_attn.to_out", att[Mp:], inner, Mv, vt, h, R=vt, ldr=h)
+            self._mlp_residual(pk, p, vt, Mv, xn[Mp:], hbuf[Mp:])
+            # virtual self attention, per frame
+            p = f"{u}space_virtual_blocks.{i}"
+            hip.layernorm(vt, h, None, None, xn[Mp:], h, Mv, h, 1e-6)
+            self._lin(pk, p + ".attn.qkv", xn[Mp:], h, Mv, qkv[Mp:], 3 * inner)
+            hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, nv, H,
+                          dh)
+            self._lin(pk, p + ".attn.to_out", att[Mp:], inner, Mv, vt, h, R=vt, ldr=h)
+            self._mlp_residual(pk, p, vt, Mv, xn[Mp:], hbuf[Mp:])
+            # point <- virtual cross attention, per frame
+            p = f"{u}space_point2virtual_blocks.{i}"
+            hip.layernorm(pt, h, None, None, xn[:Mp], h, Mp, h, 1e-6)
+            hip.layernorm(vt, h, *pk[p + ".norm_context"], ctx[Mp:], h, Mv, h, 1e-5)
+            self._lin(pk, p + ".cross_attn.to_q", xn[:Mp], h, Mp, qkv[:Mp], 3 * inner)
+            self._lin(pk, p + ".cross_attn.to_kv", ctx[Mp:], h, Mv, qkv[Mp:, inner:], 3 * inner)
+            hip.attention(qkv[:Mp], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[:Mp], inner, S, n, nv, H,
+                          dh)
+            self._lin(pk, p + ".cross_attn.to_out", att[:Mp], inner, Mp, pt, h, R=pt, ldr=h)
+            self._mlp_residual(pk, p, pt, Mp, xn[:Mp], hbuf[:Mp])
+        od = self.out_dim
+        ldh = _round_up(od, 4)
+        h1 = torch.zeros(Mp, ldh, device=dev)
+        h2 = torch.zeros(Mp, ldh, device=dev)
+        self._lin(pk, u + "flow_head.0", pt, h, Mp, h1, ldh, hip.ACT_RELU)
+        self._lin(pk, u + "flow_head.2", h1, ldh, Mp, h2, ldh, hip.ACT_RELU)
+        self._lin(pk, u + "flow_head.4", h2, ldh, Mp, delta, ldd)
+
+    def update_former(self, x):
+        """EfficientUpdateFormer.forward on tokens x (1,N,S,D) -> (1,N,S,3+C) (test / parity entry)."""
+        _, n, S, D = x.shape
+        assert S == self.S and D == self.updateformer_input_dim
+        pk = self._pack(x.device)
+        ldx = _round_up(D, 4)
+        xp = torch.zeros(n * S, ldx, device=x.device)
+        xp[:, :D] = x.reshape(n * S, D)
+        ldd = _round_up(self.out_dim, 4)
+        delta = torch.zeros(n * S, ldd, device=x.device)
+        self._update_former(pk, xp, ldx, n, delta, ldd)
+        return delta[:, :self.out_dim].reshape(1, n, S, self.out_dim)
+
+    # ------------------------------------------------------------------ one window (mvtracker.py:244-410)
+    def refine_window(self, store, frame0, coords, vis_init, track_mask, feat_init, iters=4, nan_flag=None, trace=None):
+        """Iterative refinement of one window.
+
+        coords (n,S,3) world xyz (updated in place and returned per iteration), vis_init (n,S) logits,
+        track_mask (n,S) {0,1}, feat_init (n,S,C).  Window slot s reads frame min(frame0+s, T-1).
+        Returns (list of coords per iteration, vis logits (n,S))."""
+        S, C, K, L, E = self.S, self.latent_dim, self.corr_neighbors, self.corr_n_levels, self.flow_embed_dim
+        n = coords.shape[0]
+        dev = coords.device
+        pk = self._pack(dev)
+        D = self.updateformer_input_dim
+        T = store["T"]
+        Fc = L * K * 4
+        coords = coords.contiguous().clone()
+        ffeats = feat_init.contiguous().clone()
+        mask_vis = torch.stack([track_mask.float(), vis_init.float()], dim=2).contiguous()
+        pos = torch.empty(n, D, device=dev)
+        hip.pos_embed(coords, n, S, D, _round_up(D, 6), pos)
+        fcorr = torch.empty(n, S, Fc, device=dev)
+        ldx = _round_up(D, 4)
+        x = torch.zeros(n * S, ldx, device=dev)
+        ldd = _round_up(self.out_dim, 4)
+        delta = torch.zeros(n * S, ldd, device=dev)
+        dn = torch.empty(n * S, C, device=dev)
+        nsegs = [self._nseg(store["P"][lvl], K) for lvl in range(L)]
+        keys = [torch.empty(n * S * nsegs[lvl] * K, device=dev, dtype=torch.int64) for lvl in range(L)]
+        idx_dbg = torch.empty(L, n, S, K, device=dev, dtype=torch.int32) if trace is not None else None
+        preds = []
+        for it in range(iters):
+            for lvl in range(L):
+                P = store["P"][lvl]
+                hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl])
+                hip.corr_gather_dot(store["xyz"][lvl], store["fvec"][lvl], P, C, ffeats, coords, keys[lvl], n, S, frame0, 1, T, K,
+                                    nsegs[lvl], fcorr, Fc, lvl * K * 4, idx_dbg[lvl] if idx_dbg is not None else None)
+            hip.token_assemble(coords, fcorr, Fc, ffeats, C, mask_vis, pos, pk["time_embed"], n, S, E, x, ldx)
+            self._update_former(pk, x, ldx, n, delta, ldd)
+            if trace is not None:
+                trace.setdefault("knn_idx", []).append(idx_dbg.clone())
+                trace.setdefault("fcorrs", []).append(fcorr.clone())
+                trace.setdefault("tokens", []).append(x[:, :D].reshape(n, S, D).clone())
+                trace.setdefault("delta", []).append(delta[:, :self.out_dim].reshape(n, S, -1).clone())
+            hip.delta_split(delta, ldd, *pk["ffeats_norm"], coords, dn, n * S, C, nan_flag)
+            self._lin(pk, "ffeats_updater.0", dn, C, n * S, ffeats, C, hip.ACT_GELU_ERF, R=ffeats, ldr=C)
+            preds.append(coords.clone())
+        vis = torch.empty(n, S, device=dev)
+        hip.rowdot(ffeats, C, *pk["vis"], vis, n * S, C)
+        if trace is not None:
+            trace["ffeats"] = ffeats
+        return preds, vis
+
+    # ------------------------------------------------------------------ forward (mvtracker.py:412-732)
+    @torch.no_grad()
+    def forward(
+            self,
+            rgbs,
+            depths,
+            query_points,
+            intrs,
+            extrs,
+            iters=4,
+            image_features=None,
+            is_train=False,
+            save_debug_logs=False,
+            debug_logs_path="",
+            save_rerun_logs: bool = False,
+            save_rerun_logs_output_rrd_path: Optional[str] = None,
+            frame_store: Optional[dict] = None,
+            **kwargs,
+    ):
+        if is_train:
+            raise NotImplementedError("inference only: the MI355X path has no backward")
+        if save_debug_logs or save_rerun_logs:
+            log.warning("save_debug_logs / save_rerun_logs are host-side visualisation hooks of the reference; ignored")
+        batch_size, num_views, num_frames, _, height, width = rgbs.shape
+        _, num_points, _ = query_points.shape
+        assert rgbs.shape == (batch_size, num_views, num_frames, 3, height, width)
+        assert depths.shape == (batch_size, num_views, num_frames, 1, height, width)
+        assert query_points.shape == (batch_size, num_points, 4)
+        assert intrs.shape == (batch_size, num_views, num_frames, 3, 3)
+        assert extrs.shape == (batch_size, num_views, num_frames, 3, 4)
+        assert batch_size == 1, "Batch size > 1 is not supported yet"
+        hip.require_device(rgbs)
+        dev = rgbs.device
+        V, T, S, C, N = num_views, num_frames, self.S, self.latent_dim, num_points
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        rgbs, depths, intrs, extrs, query_points = map(f32, (rgbs[0], depths[0], intrs[0], extrs[0], query_points[0]))
+
+        # the one host sync of the call: integer query frames (mvtracker.py:489, truncation toward zero)
+        qt_dev = query_points[:, 0].long()
+        qt = qt_dev.cpu().numpy()
+        order = np.argsort(qt, kind="stable")  # mvtracker.py:514 (order among equal t is unobservable)
+        inv_order = np.argsort(order, kind="stable")
+        qt_s = qt[order]
+        order_d = torch.from_numpy(order).to(dev)
+        inv_d = torch.from_numpy(inv_order).to(dev)
+        qxyz = query_points[order_d, 1:].contiguous()  # (N,3), sorted by start frame
+
+        traj = torch.zeros(T, N, 3, device=dev)
+        vis_prob = torch.zeros(T, N, device=dev)
+        vis_logit = torch.zeros(T, N, device=dev)
+        feat_init = torch.zeros(N, C, device=dev)
+        nan_flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        frames = torch.arange(T, device=dev)
+        track_mask = (frames[:, None] >= qt_dev[order_d][None, :])  # (T,N) bool, mvtracker.py:505-507
+        coords_init = qxyz[:, None, :].repeat(1, S, 1)  # (N,S,3), mvtracker.py:510
+        vis_init = torch.full((N, S), 10.0, device=dev)  # mvtracker.py:511
+
+        w = int(qt_s.min())
+        windows = []
+        if w < T - S // 2:
+            store = frame_store if frame_store is not None else self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0))
+        p0 = 0
+        coords = vis = None
+        while w < T - S // 2:  # mvtracker.py:537
+            p1 = int(np.searchsorted(qt_s, w + S, side="left"))  # number of queries with t < w+S (:538-540)
+            assert p1 > 0
+            S_local = min(S, T - w)
+            if p1 > p0:  # feature init: 1-NN in the fused level-0 cloud of the query frame (:607-645)
+                P0 = store["P"][0]
+                ns = self._nseg(P0, 1)
+                a = p0
+                while a < p1:
+                    t = int(qt_s[a])
+                    b = int(np.searchsorted(qt_s, t, side="right"))
+                    b = min(b, p1)
+                    keys = torch.empty((b - a) * ns, device=dev, dtype=torch.int64)
+                    hip.knn_scan(store["xyz"][0], P0, qxyz[a:b], b - a, 1, t, 0, T, 1, ns, keys)
+                    hip.knn1_gather(store["fvec"][0], P0, C, keys, b - a, ns, t, feat_init[a:b])
+                    a = b
+            if p0 > 0:  # carry-over from the previous window (:648-655); vis is the previous LOGIT
+                last_c = coords[-1][:p0, S // 2:]
+                coords_init[:p0, :S // 2] = last_c
+                coords_init[:p0, S // 2:] = last_c[:, -1:].expand(-1, S - S // 2, -1)
+                last_v = vis[:p0, S // 2:]
+                vis_init[:p0, :S // 2] = last_v
+                vis_init[:p0, S // 2:] = last_v[:, -1:].expand(-1, S - S // 2)
+            tm = track_mask[w:w + S, :p1]
+            if S_local < S:
+                tm = torch.cat([tm, tm[-1:].expand(S - S_local, -1)], 0)
+            coords, vis = self.refine_window(store, w, coords_init[:p1], vis_init[:p1], tm.t(), feat_init[:p1, None, :].expand(-1, S, -1),
+                                             iters=iters, nan_flag=nan_flag)
+            traj[w:w + S, :p1] = coords[-1][:, :S_local].permute(1, 0, 2)  # :692-693
+            vis_logit[w:w + S, :p1] = vis[:, :S_local].t()
+            vis_prob[w:w + S, :p1] = torch.sigmoid(vis[:, :S_local].t())
+            track_mask[:w + S, :p1] = False  # :695
+            windows.append((w, p1))
+            w += S // 2
+            p0 = p1
+        self.last_windows = windows
+        self.last_vis_logits = vis_logit[:, inv_d][None]
+        self.last_nan_flag = nan_flag
+        results = {
+            "traj_e": traj[:, inv_d][None],
+            "feat_init": feat_init[None, None].expand(1, S, -1, -1),
+            "vis_e": vis_prob[:, inv_d][None],
+        }
+        return results
+
+    def check_finite(self):
+        """Deferred NaN guard (reference mvtracker.py:401-404): raises if the last forward produced NaN tracks."""
+        if int(self.last_nan_flag.item()) != 0:
+            raise FloatingPointError("Got NaN values in coords, perhaps the training exploded")

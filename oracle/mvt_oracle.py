@@ -136,7 +136,7 @@ def state_dict_shapes(cfg: TrackerConfig) -> Dict[str, Tuple[int, ...]]:
     return s
 
 
-def make_weights(cfg: TrackerConfig, seed: int = 0, delta_scale: float = 0.05) -> Dict[str, Tensor]:
+def make_weights(cfg: TrackerConfig, seed: int = 0, delta_scale: float = 0.005) -> Dict[str, Tensor]:
     """Seeded synthetic weights (SURVEY.md section 8c recipe); identical on every platform.
 
     Each tensor is drawn from ``np.random.default_rng(crc32(key) ^ seed)``: matrices / conv

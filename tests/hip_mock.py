@@ -1,0 +1,246 @@
+"""Torch-CPU stand-ins for the wrappers of mvtracker_amd.hip -- TEST INFRASTRUCTURE ONLY.
+
+The build container has no GPU, so the host-side sequencing of mvtracker_amd.tracker /
+.predictor (window bookkeeping, buffer strides, weight packing, launch order) is exercised on
+CPU by monkeypatching the ctypes wrappers with the functions below, each of which restates the
+documented contract of one entry point of include/mvtracker_hip.h with plain torch ops.  The
+product never imports this module; on the GPU box the `-m gpu` tests run the real library.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _v(t, rows, cols, ld):
+    return torch.as_strided(t, (rows, cols), (ld, 1))
+
+
+def _act(x, act):
+    return [lambda a: a, F.relu, lambda a: F.gelu(a, approximate="tanh"), F.gelu][act](x)
+
+
+def gemm(A, lda, Wt, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=0):
+    assert lda % 4 == 0 and ldw % 32 == 0 and ldw >= K
+    a = _v(A, M, K, lda)
+    w = _v(Wt, N, ldw, ldw)[:, :K]
+    assert float(_v(Wt, N, ldw, ldw)[:, K:].abs().sum()) == 0.0
+    y = a @ w.t()
+    if bias is not None:
+        y = y + bias[:N]
+    y = _act(y, act)
+    if R is not None:
+        y = y + _v(R, M, N, ldr)
+    _v(Cm, M, N, ldc).copy_(y)
+
+
+def conv2d(x, wt, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0):
+    xi = torch.as_strided(x, (n, H, W, Cin), (H * W * Cin, W * Cin, Cin, 1)).permute(0, 3, 1, 2)
+    if Cin == 4:
+        w = torch.as_strided(wt, (Cout, KH, 8, 4), (KH * 32, 32, 4, 1))[:, :, :KW, :].permute(0, 3, 1, 2)
+    else:
+        w = torch.as_strided(wt, (Cout, KH, KW, Cin), (KH * KW * Cin, KW * Cin, Cin, 1)).permute(0, 3, 1, 2)
+    y = _act(F.conv2d(xi, w, bias, stride=stride, padding=pad), act)
+    Ho, Wo = y.shape[-2:]
+    torch.as_strided(out, (n, Ho, Wo, Cout), (Ho * Wo * ldo, Wo * ldo, ldo, 1)).copy_(y.permute(0, 2, 3, 1))
+
+
+def rgb_to_nhwc4(rgbs, out, V, T, H, W, t0, nt):
+    x = 2 * (rgbs[:, t0:t0 + nt] / 255.0) - 1.0  # (V,nt,3,H,W)
+    o = torch.as_strided(out, (nt, V, H, W, 4), (V * H * W * 4, H * W * 4, W * 4, 4, 1))
+    o[..., :3] = x.permute(1, 0, 3, 4, 2)
+    o[..., 3] = 0
+
+
+def resize_nearest(x, out, planes, Hi, Wi, Ho, Wo):
+    y = F.interpolate(x.reshape(1, planes, Hi, Wi), (Ho, Wo), mode="nearest")
+    out.reshape(-1)[:planes * Ho * Wo].copy_(y.reshape(-1))
+
+
+def instnorm_stats(x, ldx, partial, mean_rstd, n, HW, Cc):
+    xv = torch.as_strided(x, (n, HW, Cc), (HW * ldx, ldx, 1)).double()
+    mean = xv.mean(1)
+    var = (xv * xv).mean(1) - mean * mean
+    st = torch.as_strided(mean_rstd, (n, Cc, 2), (Cc * 2, 2, 1))
+    st[..., 0] = mean.float()
+    st[..., 1] = (1.0 / torch.sqrt(var.clamp_min(0) + 1e-5)).float()
+
+
+def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc):
+    xv = torch.as_strided(x, (n, HW, Cc), (HW * Cc, Cc, 1))
+    st = torch.as_strided(mean_rstd, (n, 1, Cc, 2), (Cc * 2, 0, 2, 1))
+    o = F.relu((xv - st[..., 0]) * st[..., 1])
+    if skip is not None:
+        k = torch.as_strided(skip, (n, HW, Cc), (HW * Cc, Cc, 1))
+        if skip_stats is not None:
+            ks = torch.as_strided(skip_stats, (n, 1, Cc, 2), (Cc * 2, 0, 2, 1))
+            k = (k - ks[..., 0]) * ks[..., 1]
+        o = F.relu(k + o)
+    torch.as_strided(y, (n, HW, Cc), (HW * Cc, Cc, 1)).copy_(o)
+
+
+def resize_bilinear_ac(src, dst, n, Hs, Ws, Cc, Hd, Wd, ldd, c_off):
+    s = torch.as_strided(src, (n, Hs, Ws, Cc), (Hs * Ws * Cc, Ws * Cc, Cc, 1)).permute(0, 3, 1, 2)
+    y = F.interpolate(s, (Hd, Wd), mode="bilinear", align_corners=True)
+    torch.as_strided(dst, (n, Hd, Wd, Cc), (Hd * Wd * ldd, Wd * ldd, ldd, 1), dst.storage_offset() + c_off).copy_(y.permute(0, 2, 3, 1))
+
+
+def invert_cameras(intrs, extrs, kinv, einv, n):
+    k = torch.inverse(intrs.reshape(n, 3, 3).double())
+    e = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1)
+    e[:, :3] = extrs.reshape(n, 3, 4).double()
+    kinv.reshape(n, 9).copy_(k.reshape(n, 9).float())
+    einv.reshape(n, 12).copy_(torch.inverse(e)[:, :3].reshape(n, 12).float())
+
+
+def depth_subsample(depths, out, V, T, H, W, s):
+    d = depths.reshape(V, T, H, W)[:, :, ::s, ::s][:, :, :H // s, :W // s]
+    out.reshape(T, V, H // s, W // s).copy_(d.permute(1, 0, 2, 3))
+
+
+def avgpool2(x, out, n, h, w, Cc):
+    xi = torch.as_strided(x, (n, h, w, Cc), (h * w * Cc, w * Cc, Cc, 1)).permute(0, 3, 1, 2)
+    y = F.avg_pool2d(xi, 2, stride=2).permute(0, 2, 3, 1)
+    torch.as_strided(out, tuple(y.shape), (y.shape[1] * y.shape[2] * Cc, y.shape[2] * Cc, Cc, 1)).copy_(y)
+
+
+def unproject(depth_s, kinv, einv, xyz, V, T, hs, ws, stride, level):
+    f = 1 << level
+    h, w = hs >> level, ws >> level
+    d = depth_s.reshape(T, V, hs, ws)[:, :, ::f, ::f][:, :, :h, :w]
+    st = stride * f
+    ys = (torch.arange(h) + 0.5) * st - 0.5
+    xs = (torch.arange(w) + 0.5) * st - 0.5
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    pix = torch.stack([gx, gy, torch.ones_like(gx)], -1)
+    K = kinv.reshape(V, T, 3, 3).permute(1, 0, 2, 3)
+    E = einv.reshape(V, T, 3, 4).permute(1, 0, 2, 3)
+    cam = torch.einsum("tvij,hwj->tvhwi", K, pix) * d[..., None]
+    world = torch.einsum("tvij,tvhwj->tvhwi", E[..., :3], cam) + E[:, :, None, None, :, 3]
+    o = xyz.reshape(T, V, h, w, 4)
+    o[..., :3] = world
+    o[..., 3] = 0
+
+
+def _d2(ref, q):
+    dx = ref[None, :, 0] - q[:, None, 0]
+    dy = (ref[None, :, 1] - q[:, None, 1]).double()
+    dz = (ref[None, :, 2] - q[:, None, 2]).double()
+    acc = (dy * dy + (dx * dx).double()).float()
+    return (dz * dz + acc.double()).float()
+
+
+def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys):
+    X = torch.as_strided(xyz, (T, Pn, 4), (Pn * 4, 4, 1))
+    c = torch.as_strided(coords, (N, S, 3), (S * 3, 3, 1))
+    kv = torch.as_strided(keys, (N, S, nseg, K), (S * nseg * K, nseg * K, K, 1))
+    per = (Pn + nseg - 1) // nseg
+    for s in range(S):
+        f = min(frame0 + s * frame_step, T - 1)
+        d2 = _d2(X[f, :, :3], c[:, s])
+        key = (d2.view(torch.int32).to(torch.int64) << 32) | torch.arange(Pn)[None]
+        for g in range(nseg):
+            seg = key[:, g * per:min(Pn, (g + 1) * per)]
+            kv[:, s, g] = torch.topk(seg, K, dim=1, largest=False, sorted=True).values
+
+
+def corr_gather_dot(xyz, fvec, Pn, Cc, targets, coords, keys, N, S, frame0, frame_step, T, K, nseg, out, ldo, o_off,
+                    idx_out=None):
+    X = torch.as_strided(xyz, (T, Pn, 4), (Pn * 4, 4, 1))
+    Fv = torch.as_strided(fvec, (T, Pn, Cc), (Pn * Cc, Cc, 1))
+    kv = torch.as_strided(keys, (N, S, nseg * K), (S * nseg * K, nseg * K, 1))
+    idx = torch.sort(kv, dim=2).values[:, :, :K] & 0xFFFFFFFF
+    tg = torch.as_strided(targets, (N, S, Cc), (S * Cc, Cc, 1))
+    c = torch.as_strided(coords, (N, S, 3), (S * 3, 3, 1))
+    o = torch.as_strided(out, (N, S, K, 4), (S * ldo, ldo, 4, 1), out.storage_offset() + o_off)
+    for s in range(S):
+        f = min(frame0 + s * frame_step, T - 1)
+        nf = Fv[f][idx[:, s]]
+        o[:, s, :, 0] = torch.einsum("nc,nkc->nk", tg[:, s], nf) / math.sqrt(Cc)
+        o[:, s, :, 1:] = X[f][idx[:, s]][..., :3] - c[:, s, None]
+    if idx_out is not None:
+        idx_out.reshape(N, S, K).copy_(idx.int())
+
+
+def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):
+    idx = keys.reshape(n, nseg).min(1).values & 0xFFFFFFFF
+    Fv = torch.as_strided(fvec, (frame + 1, Pn, Cc), (Pn * Cc, Cc, 1))
+    feat_out.reshape(n, Cc).copy_(Fv[frame][idx])
+    if idx_out is not None:
+        idx_out.reshape(n).copy_(idx.int())
+
+
+def pos_embed(coords, N, S, D, dim_padded, pos):
+    import numpy as np
+    A = dim_padded // 3
+    omega = 1.0 / 10000 ** (np.arange(A // 2, dtype=np.float64) / (A / 2.0))
+    c0 = torch.as_strided(coords, (N, 3), (S * 3, 1)).double().numpy()
+    e = []
+    for a in range(3):
+        o = c0[:, a:a + 1] * omega[None]
+        e += [np.sin(o), np.cos(o)]
+    pos.reshape(N, D).copy_(torch.from_numpy(np.concatenate(e, 1)[:, :D]).float())
+
+
+def token_assemble(coords, fcorr, Fc, ffeats, Cc, mask_vis, pos, time_embed, N, S, E, x, ldx):
+    c = coords.reshape(N, S, 3)
+    fl = c - c[:, :1]
+    div = (torch.arange(0, E, 2, dtype=torch.float32) * (1000.0 / E)).reshape(1, 1, E // 2)
+    parts = []
+    for a in range(3):
+        pe = torch.zeros(N, S, E)
+        pe[:, :, 0::2] = torch.sin(fl[:, :, a:a + 1] * div)
+        pe[:, :, 1::2] = torch.cos(fl[:, :, a:a + 1] * div)
+        parts.append(pe)
+    D = 3 * E + 3 + Fc + Cc + 2
+    t = torch.cat(parts + [fl, fcorr.reshape(N, S, Fc), ffeats.reshape(N, S, Cc), mask_vis.reshape(N, S, 2)], 2)
+    t = t + pos.reshape(N, 1, D) + time_embed.reshape(1, S, D)
+    torch.as_strided(x, (N * S, D), (ldx, 1)).copy_(t.reshape(N * S, D))
+
+
+def delta_split(delta, ldd, gw, gb, coords, dn, rows, Cc, nan_flag=None):
+    d = _v(delta, rows, 3 + Cc, ldd)
+    c = coords.reshape(-1)[:rows * 3].reshape(rows, 3)
+    c += d[:, :3]
+    dn.reshape(-1)[:rows * Cc].reshape(rows, Cc).copy_(F.group_norm(d[:, 3:], 1, gw, gb, 1e-5))
+    if nan_flag is not None and bool(torch.isnan(c).any()):
+        nan_flag.fill_(1)
+
+
+def rowdot(x, ldx, w, b, out, rows, Cc):
+    out.reshape(-1)[:rows].copy_(_v(x, rows, Cc, ldx) @ w[:Cc] + b[0])
+
+
+def layernorm(x, ldx, w, b, y, ldy, rows, Cc, eps):
+    _v(y, rows, Cc, ldy).copy_(F.layer_norm(_v(x, rows, Cc, ldx), (Cc,), w, b, eps))
+
+
+def attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
+    Q = torch.as_strided(q, (groups, nq, heads, dh), (q_gs * ldq, q_is * ldq, dh, 1)).permute(0, 2, 1, 3)
+    Kt = torch.as_strided(k, (groups, nk, heads, dh), (k_gs * ldkv, k_is * ldkv, dh, 1)).permute(0, 2, 1, 3)
+    Vt = torch.as_strided(v, (groups, nk, heads, dh), (k_gs * ldkv, k_is * ldkv, dh, 1)).permute(0, 2, 1, 3)
+    y = F.scaled_dot_product_attention(Q, Kt, Vt).permute(0, 2, 1, 3)
+    torch.as_strided(o, (groups, nq, heads, dh), (q_gs * ldo, q_is * ldo, dh, 1)).copy_(y)
+
+
+def broadcast_rows(v, x, ld, n, S, Cc):
+    torch.as_strided(x, (n, S, Cc), (S * ld, ld, 1)).copy_(v.reshape(n, 1, Cc).expand(n, S, Cc))
+
+
+def window_corr(fmap, targets, coords, out, BS, N, Cc, h, w, level, radius, ldo, o_off):
+    raise NotImplementedError("window_corr is only exercised on the GPU")
+
+
+def require_device(t):
+    return None
+
+
+def install(monkeypatch):
+    """Patch mvtracker_amd.hip so that the host code runs on CPU tensors."""
+    import sys
+    from mvtracker_amd import hip
+    me = sys.modules[__name__]
+    for name in ("gemm conv2d rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
+                 "depth_subsample avgpool2 unproject knn_scan corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
+                 "rowdot layernorm attention broadcast_rows window_corr require_device").split():
+        monkeypatch.setattr(hip, name, getattr(me, name))

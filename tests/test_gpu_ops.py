@@ -1,0 +1,365 @@
+"""Parity of every entry point of libmvtracker_hip.so against the oracle / plain torch fp32-fp64
+references on identical inputs.  Runs on the MI355X box only (`-m gpu`); all calls go through the C ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mvtracker_amd import synth  # noqa: E402
+from oracle import mvt_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mvtracker_amd import hip as h
+    assert torch.cuda.is_available()
+    return h
+
+
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def G(a):
+    return (a if isinstance(a, torch.Tensor) else T(a)).to(DEV).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def pad_w(w):
+    n, k = w.shape
+    wp = torch.zeros(n, (k + 31) // 32 * 32)
+    wp[:, :k] = w
+    return wp
+
+
+# ----------------------------------------------------------------------------------------- GEMM / conv
+@pytest.mark.parametrize("M,N,K,act,res", [(300, 256, 581, 0, False), (1000, 131, 256, 1, False), (768, 288, 256, 0, False),
+                                           (517, 1024, 256, 2, False), (400, 256, 1024, 0, True), (130, 128, 128, 3, True),
+                                           (64, 64, 32, 0, False), (2000, 864, 256, 0, False), (33, 131, 131, 1, False)])
+def test_gemm(hip, M, N, K, act, res):
+    g = torch.Generator().manual_seed(M + N + K)
+    lda = (K + 3) // 4 * 4
+    A = torch.zeros(M, lda)
+    A[:, :K] = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g) if res else None
+    ref = A[:, :K].double() @ W.double().t() + b.double()
+    ref = [lambda x: x, F.relu, lambda x: F.gelu(x, approximate="tanh"), F.gelu][act](ref)
+    if res:
+        ref = ref + R.double()
+    ldc = N + 5
+    C = torch.full((M, ldc), 7.0, device=DEV)
+    Wp = G(pad_w(W))
+    hip.gemm(G(A), lda, Wp, Wp.shape[1], G(b), G(R) if res else None, N, C, ldc, M, N, K, act)
+    torch.cuda.synchronize()
+    assert rel_err(C[:, :N], ref) < 2e-6
+    assert bool((C[:, N:] == 7.0).all())  # nothing written outside the N columns
+
+
+CONVS = [  # n, H, W, Cin, Cout, k, stride, pad
+    (2, 64, 96, 3, 64, 7, 2, 3), (2, 33, 47, 64, 64, 3, 1, 1), (1, 33, 47, 64, 96, 3, 2, 1), (2, 30, 30, 96, 128, 1, 2, 0),
+    (1, 16, 24, 416, 256, 3, 1, 1), (3, 9, 11, 256, 128, 1, 1, 0), (1, 20, 20, 128, 128, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d(hip, cfg):
+    n, H, W, Cin, Cout, k, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p)
+    if Cin == 3:
+        x4 = torch.zeros(n, H, W, 4)
+        x4[..., :3] = x.permute(0, 2, 3, 1)
+        wt = torch.zeros(Cout, 7, 8, 4)
+        wt[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        xin, wt, cin = x4, wt.reshape(Cout, 224), 4
+    else:
+        xin, wt, cin = x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).contiguous(), Cin
+    Ho, Wo = ref.shape[-2:]
+    out = torch.empty(n, Ho, Wo, Cout, device=DEV)
+    hip.conv2d(G(xin), G(wt), G(b), out, n, H, W, cin, Cout, k, k, s, p, Cout)
+    torch.cuda.synchronize()
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 2e-6
+
+
+def test_conv2d_rejects_bad_args(hip):
+    x = torch.zeros(1, 8, 8, 48, device=DEV)
+    with pytest.raises(hip.HipError):
+        hip.conv2d(x, x, None, x, 1, 8, 8, 48, 16, 3, 3, 1, 1, 16)  # Cin % 32 != 0
+
+
+# ----------------------------------------------------------------------------------------- encoder-side kernels
+def test_rgb_to_nhwc4(hip):
+    V, Tn, H, W = 2, 5, 12, 20
+    rgb = torch.randint(0, 256, (V, Tn, 3, H, W)).float()
+    out = torch.empty(3, V, H, W, 4, device=DEV)
+    hip.rgb_to_nhwc4(G(rgb), out, V, Tn, H, W, 1, 3)
+    ref = (2 * (rgb[:, 1:4] / 255.0) - 1.0).permute(1, 0, 3, 4, 2)
+    assert torch.equal(out[..., :3].cpu(), ref) and float(out[..., 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(480, 640, 384, 512), (37, 53, 64, 96), (128, 128, 128, 128)])
+def test_resize_nearest(hip, shape):
+    Hi, Wi, Ho, Wo = shape
+    x = torch.randn(6, Hi, Wi)
+    out = torch.empty(6, Ho, Wo, device=DEV)
+    hip.resize_nearest(G(x), out, 6, Hi, Wi, Ho, Wo)
+    assert torch.equal(out.cpu(), F.interpolate(x[None], (Ho, Wo), mode="nearest")[0])
+
+
+@pytest.mark.parametrize("C,HW", [(64, 32 * 48), (96, 16 * 24), (128, 999), (256, 64)])
+def test_instnorm(hip, C, HW):
+    n = 3
+    x = torch.randn(n, HW, C) * 2 + 0.5
+    skip = torch.randn(n, HW, C)
+    xg = G(x)
+    partial = torch.empty(n * hip.IN_SLABS * C * 2, device=DEV, dtype=torch.float64)
+    st = torch.empty(n, C, 2, device=DEV)
+    hip.instnorm_stats(xg, C, partial, st, n, HW, C)
+    y = torch.empty_like(xg)
+    hip.instnorm_apply(xg, st, None, None, y, n, HW, C)
+    ref = F.relu(F.instance_norm(x.permute(0, 2, 1).double(), eps=1e-5)).permute(0, 2, 1)
+    assert (y.cpu().double() - ref).abs().max() < 1e-5
+    hip.instnorm_apply(xg, st, G(skip), None, y, n, HW, C)
+    assert (y.cpu().double() - F.relu(skip.double() + ref)).abs().max() < 1e-5
+    hip.instnorm_apply(xg, st, G(skip), st, y, n, HW, C)  # skip normalised with (here: the same) statistics
+    sk = (skip.double() - st.cpu()[:, None, :, 0].double()) * st.cpu()[:, None, :, 1].double()
+    assert (y.cpu().double() - F.relu(sk + ref)).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("Hs,Ws,Hd,Wd", [(32, 48, 16, 24), (8, 12, 16, 24), (16, 24, 16, 24), (4, 6, 16, 24)])
+def test_resize_bilinear_ac(hip, Hs, Ws, Hd, Wd):
+    n, C = 2, 64
+    x = torch.randn(n, C, Hs, Ws)
+    dst = torch.zeros(n, Hd, Wd, 160, device=DEV)
+    hip.resize_bilinear_ac(G(x.permute(0, 2, 3, 1)), dst, n, Hs, Ws, C, Hd, Wd, 160, 32)
+    ref = F.interpolate(x, (Hd, Wd), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert (dst[..., 32:96].cpu() - ref).abs().max() < 1e-5
+    assert float(dst[..., :32].abs().max()) == 0 and float(dst[..., 96:].abs().max()) == 0
+
+
+# ----------------------------------------------------------------------------------------- frame store
+def test_frame_store_kernels(hip, golden):
+    g = golden("pyramid_small")
+    fm, ds_ref = T(g["fmaps"]), T(g["depths_strided"])  # (1,2,3,8,16,16), (1,2,3,1,16,16)
+    V, Tn, C = 2, 3, 8
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=3, H=64, W=64, N=4, invalid_frac=0.02)
+    ds = torch.empty(Tn, V, 16, 16, device=DEV)
+    hip.depth_subsample(G(clip["depths"][0]), ds, V, Tn, 64, 64, 4)
+    assert torch.equal(ds.cpu(), ds_ref[0, :, :, 0].permute(1, 0, 2, 3))
+    kinv = torch.empty(V * Tn, 9, device=DEV)
+    einv = torch.empty(V * Tn, 12, device=DEV)
+    hip.invert_cameras(G(g["intrs"]).reshape(-1, 9), G(g["extrs"]).reshape(-1, 12), kinv, einv, V * Tn)
+    f = G(fm[0].permute(1, 0, 3, 4, 2))  # (T,V,h,w,C)
+    h = 16
+    for lvl in range(3):
+        if lvl > 0:
+            nxt = torch.empty(Tn, V, h // 2, h // 2, C, device=DEV)
+            hip.avgpool2(f, nxt, Tn * V, h, h, C)
+            f, h = nxt, h // 2
+        xyz = torch.empty(Tn, V, h, h, 4, device=DEV)
+        hip.unproject(ds, kinv, einv, xyz, V, Tn, 16, 16, 4, lvl)
+        torch.cuda.synchronize()
+        assert np.abs(xyz[..., :3].reshape(Tn, -1, 3).cpu().numpy() - g[f"xyz{lvl}"]).max() < 2e-5
+        assert np.abs(f.reshape(Tn, -1, C).cpu().numpy() - g[f"fvec{lvl}"]).max() < 1e-6
+
+
+# ----------------------------------------------------------------------------------------- kNN + correlation
+def _run_corr(hip, xyz, fvec, targets, coords, K, nseg):
+    B, P, C = fvec.shape
+    M = targets.shape[1]
+    x4 = torch.zeros(B, P, 4)
+    x4[..., :3] = xyz
+    # library layout: tracks major -> use N = M, S = B (slot s reads frame s)
+    tg = G(targets.permute(1, 0, 2))
+    cd = G(coords.permute(1, 0, 2))
+    keys = torch.empty(M * B * nseg * K, device=DEV, dtype=torch.int64)
+    hip.knn_scan(G(x4), P, cd, M, B, 0, 1, B, K, nseg, keys)
+    out = torch.zeros(M, B, K * 4, device=DEV)
+    idx = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
+    hip.corr_gather_dot(G(x4), G(fvec), P, C, tg, cd, keys, M, B, 0, 1, B, K, nseg, out, K * 4, 0, idx)
+    torch.cuda.synchronize()
+    return out.reshape(M, B, K, 4).permute(1, 0, 2, 3).cpu(), idx.permute(1, 0, 2).cpu().long(), keys
+
+
+def test_corr_sample_golden(hip, golden):
+    g = golden("corr_sample_small")
+    out, idx, _ = _run_corr(hip, T(g["xyz"]), T(g["fvec"]), T(g["targets"]), T(g["coords"]), 16, 1)
+    assert np.array_equal(idx.numpy(), g["idx_exact"])  # integer indices bit-exact vs the reference
+    assert np.abs(out.numpy() - g["out_exact"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("P,K,nseg,M", [(20000, 16, 2, 37), (65536, 16, 4, 16), (5000, 1, 1, 20), (40000, 1, 4, 9), (16, 16, 1, 5),
+                                        (1000, 8, 1, 64)])
+def test_knn_exact_vs_oracle(hip, P, K, nseg, M):
+    g = torch.Generator().manual_seed(P + K)
+    B, C = 2, 128
+    xyz = torch.rand(B, P, 3, generator=g) * 4 - 2
+    fvec = torch.randn(B, P, C, generator=g)
+    tg = torch.randn(B, M, C, generator=g)
+    cd = torch.rand(B, M, 3, generator=g) * 4 - 2
+    out, idx, keys = _run_corr(hip, xyz, fvec, tg, cd, K, nseg)
+    ref, ridx = O.corr_sample(xyz, fvec, tg, cd, K, 1, True, False, "exact", return_idx=True)
+    assert torch.equal(idx, ridx)
+    assert (out - ref).abs().max() < 2e-5
+    kv = keys.reshape(M, B, nseg, K).cpu()
+    assert bool((kv[..., 1:] > kv[..., :-1]).all())  # every per-segment list strictly ascending (sortedness)
+
+
+def test_knn_duplicate_points_tie_break(hip):
+    # exact ties: the lower index must win (ordering by (d2, index))
+    P, K = 300, 16
+    xyz = torch.zeros(1, P, 3)
+    xyz[0, :, 0] = torch.arange(P) // 4  # groups of four identical points
+    fvec = torch.randn(1, P, 128)
+    cd = torch.tensor([[[10.2, 0.0, 0.0]]])
+    _, idx, _ = _run_corr(hip, xyz, fvec, torch.randn(1, 1, 128), cd, K, 1)
+    _, ridx = O.corr_sample(xyz, fvec, torch.randn(1, 1, 128), cd, K, 1, True, False, "exact", return_idx=True)
+    assert torch.equal(idx, ridx)
+
+
+def test_knn1_gather(hip):
+    g = torch.Generator().manual_seed(5)
+    P, C, n, nseg = 30000, 128, 33, 3
+    xyz = torch.zeros(2, P, 4)
+    xyz[..., :3] = torch.rand(2, P, 3, generator=g)
+    fvec = torch.randn(2, P, C, generator=g)
+    q = torch.rand(n, 3, generator=g)
+    keys = torch.empty(n * nseg, device=DEV, dtype=torch.int64)
+    hip.knn_scan(G(xyz), P, G(q), n, 1, 1, 0, 2, 1, nseg, keys)
+    feat = torch.empty(n, C, device=DEV)
+    idx = torch.empty(n, device=DEV, dtype=torch.int32)
+    hip.knn1_gather(G(fvec), P, C, keys, n, nseg, 1, feat, idx)
+    _, ridx = O.knn_exact(1, xyz[1:2, :, :3], q[None])
+    assert torch.equal(idx.cpu().long(), ridx[0, :, 0])
+    assert torch.equal(feat.cpu(), fvec[1][ridx[0, :, 0]])
+
+
+@pytest.mark.parametrize("r", [3, 4])
+def test_window_corr(hip, golden, r):
+    g = golden("window_corr_small")
+    fm, tg, cd = T(g["fmaps"]), T(g["targets"]), T(g["coords"])  # (1,2,32,24,40), (1,2,10,32), (1,2,10,2)
+    pyr = O.window_corr_pyramid(fm, 3)
+    D = (2 * r + 1) ** 2
+    out = torch.zeros(2, 10, 3 * D, device=DEV)
+    for lvl, f in enumerate(pyr):
+        h, w = f.shape[-2:]
+        hip.window_corr(G(f[0].permute(0, 2, 3, 1)), G(tg[0]), G(cd[0]), out, 2, 10, 32, h, w, lvl, r, 3 * D, lvl * D)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - g[f"out_r{r}"][0]).max() < 2e-5
+
+
+# ----------------------------------------------------------------------------------------- tokens
+def test_pos_embed_and_tokens(hip, golden):
+    g = golden("embeddings")
+    c0 = T(g["coords0"]).reshape(-1, 3)
+    n, S, D = c0.shape[0], 12, 581
+    coords = c0[:, None, :].repeat(1, S, 1) + T(g["flows"][:1]).repeat(n, 1, 1) * torch.arange(n)[:, None, None]
+    coords[:, 0] = c0
+    pos = torch.empty(n, D, device=DEV)
+    hip.pos_embed(G(coords), n, S, D, 582, pos)
+    ref = g["pos_embed"].reshape(n, 582)[:, :D].astype(np.float32)
+    assert np.abs(pos.cpu().numpy() - ref).max() < 1.5e-7
+    cfg = O.TrackerConfig()
+    gen = torch.Generator().manual_seed(1)
+    fc = torch.randn(n, S, 256, generator=gen)
+    ff = torch.randn(n, S, 128, generator=gen)
+    mv = torch.randn(n, S, 2, generator=gen)
+    p_o, te = O.window_embeddings(cfg, c0, S)
+    x = torch.zeros(n * S, 584, device=DEV)
+    hip.token_assemble(G(coords), G(fc), 256, G(ff), 128, G(mv), pos, G(te[0]), n, S, 64, x, 584)
+    xo = O.assemble_tokens(cfg, coords.permute(1, 0, 2)[None], fc.permute(1, 0, 2)[None], ff.permute(1, 0, 2)[None], mv, p_o, te)
+    d = (x[:, :D].cpu().reshape(n, S, D) - xo[0]).abs()
+    assert d[..., 192:].max() < 1e-6
+    assert d[..., :192].max() < 2e-4  # sin/cos of arguments up to ~1e3 rad: fp32 argument reduction differs
+    assert float(x[:, D:].abs().max()) == 0.0
+
+
+def test_layernorm(hip):
+    x = torch.randn(1000, 256) * 3 + 1
+    w, b = torch.randn(256), torch.randn(256)
+    y = torch.empty(1000, 256, device=DEV)
+    hip.layernorm(G(x), 256, None, None, y, 256, 1000, 256, 1e-6)
+    assert (y.cpu() - F.layer_norm(x, (256,), None, None, 1e-6)).abs().max() < 1e-5
+    hip.layernorm(G(x), 256, G(w), G(b), y, 256, 1000, 256, 1e-5)
+    assert (y.cpu() - F.layer_norm(x, (256,), w, b, 1e-5)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["time", "v2p", "vself", "p2v"])
+def test_attention(hip, mode):
+    g = torch.Generator().manual_seed(3)
+    n, nv, S, H, dh = 50, 64, 12, 6, 48
+    inner = H * dh
+    M = (n + nv) * S
+    qkv = torch.randn(M, 3 * inner, generator=g)
+    out = torch.zeros(M, inner, device=DEV)
+    qg = G(qkv)
+    tok = qkv.reshape(n + nv, S, 3, H, dh)
+    Mp = n * S
+    if mode == "time":
+        hip.attention(qg, 3 * inner, S, 1, qg[:, inner:], qg[:, 2 * inner:], 3 * inner, S, 1, out, inner, n + nv, S, S, H, dh)
+        q, k, v = (tok[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).permute(0, 2, 1, 3).reshape(M, inner)
+        got = out.cpu()
+    else:
+        pq, vq = tok[:n], tok[n:]  # (n,S,3,H,dh): per frame t, items along dim 0
+        if mode == "v2p":
+            hip.attention(qg[Mp:], 3 * inner, 1, S, qg[:Mp, inner:], qg[:Mp, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, n, H, dh)
+            q, k, v = vq[:, :, 0], pq[:, :, 1], pq[:, :, 2]
+            sl = slice(Mp, M)
+        elif mode == "vself":
+            hip.attention(qg[Mp:], 3 * inner, 1, S, qg[Mp:, inner:], qg[Mp:, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, nv, H, dh)
+            q, k, v = vq[:, :, 0], vq[:, :, 1], vq[:, :, 2]
+            sl = slice(Mp, M)
+        else:
+            hip.attention(qg[:Mp], 3 * inner, 1, S, qg[Mp:, inner:], qg[Mp:, 2 * inner:], 3 * inner, 1, S, out[:Mp], inner, S, n, nv, H, dh)
+            q, k, v = pq[:, :, 0], vq[:, :, 1], vq[:, :, 2]
+            sl = slice(0, Mp)
+        # (items, S, H, dh) -> (S, H, items, dh)
+        q, k, v = (t.permute(1, 2, 0, 3).double() for t in (q, k, v))
+        ref = F.scaled_dot_product_attention(q, k, v).permute(2, 0, 1, 3).reshape(-1, inner)
+        got = out[sl].cpu()
+    torch.cuda.synchronize()
+    assert (got.double() - ref).abs().max() < 2e-6
+
+
+def test_delta_split_rowdot_broadcast(hip):
+    g = torch.Generator().manual_seed(9)
+    rows, C = 500, 128
+    delta = torch.zeros(rows, 132)
+    delta[:, :131] = torch.randn(rows, 131, generator=g)
+    gw, gb = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    coords = torch.randn(rows, 3, generator=g)
+    cg = G(coords)
+    dn = torch.empty(rows, C, device=DEV)
+    flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+    hip.delta_split(G(delta), 132, G(gw), G(gb), cg, dn, rows, C, flag)
+    assert (cg.cpu() - (coords + delta[:, :3])).abs().max() < 1e-6
+    assert (dn.cpu() - F.group_norm(delta[:, 3:131], 1, gw, gb, 1e-5)).abs().max() < 2e-5
+    assert int(flag.item()) == 0
+    delta[7, 1] = float("nan")
+    hip.delta_split(G(delta), 132, G(gw), G(gb), cg, dn, rows, C, flag)
+    assert int(flag.item()) == 1
+    w, b = torch.randn(C, generator=g), torch.randn(1, generator=g)
+    x = torch.randn(rows, C, generator=g)
+    o = torch.empty(rows, device=DEV)
+    hip.rowdot(G(x), C, G(w), G(b), o, rows, C)
+    assert (o.cpu() - (x @ w + b)).abs().max() < 1e-5
+    v = torch.randn(64, 256, generator=g)
+    xb = torch.zeros(64 * 12, 256, device=DEV)
+    hip.broadcast_rows(G(v), xb, 256, 64, 12, 256)
+    assert torch.equal(xb.cpu().reshape(64, 12, 256), v[:, None].expand(64, 12, 256))
