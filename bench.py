@@ -41,7 +41,12 @@ def cpu_baseline(args):
     """Oracle (port of the reference algorithm, CPU fallback kNN = cdist+topk) on a bounded sample."""
     from mvtracker_amd import synth
     from oracle import mvt_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, args.cpu_threads))  # the GPU box gives one GPU a 16-core CPU share
+    torch.set_num_threads(cores)
     V, T, H, W, N = 4, 12, args.cpu_hw, args.cpu_hw, 128
     clip = synth.make_clip(1234, V=V, T=T, H=H, W=W, N=N)
     cfg = O.TrackerConfig()
@@ -68,6 +73,7 @@ def main():
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-hw", type=int, default=256)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -485,6 +485,7 @@ class MVTracker(nn.Module):
             save_rerun_logs: bool = False,
             save_rerun_logs_output_rrd_path: Optional[str] = None,
             frame_store: Optional[dict] = None,
+            trace: Optional[list] = None,
             **kwargs,
     ):
         if is_train:
@@ -557,8 +558,12 @@ class MVTracker(nn.Module):
             tm = track_mask[w:w + S, :p1]
             if S_local < S:
                 tm = torch.cat([tm, tm[-1:].expand(S - S_local, -1)], 0)
+            wtrace = None
+            if trace is not None:
+                wtrace = {}
+                trace.append(wtrace)
             coords, vis = self.refine_window(store, w, coords_init[:p1], vis_init[:p1], tm.t(), feat_init[:p1, None, :].expand(-1, S, -1),
-                                             iters=iters, nan_flag=nan_flag)
+                                             iters=iters, nan_flag=nan_flag, trace=wtrace)
             traj[w:w + S, :p1] = coords[-1][:, :S_local].permute(1, 0, 2)  # :692-693
             vis_logit[w:w + S, :p1] = vis[:, :S_local].t()
             vis_prob[w:w + S, :p1] = torch.sigmoid(vis[:, :S_local].t())

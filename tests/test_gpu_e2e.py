@@ -125,7 +125,7 @@ def test_forward_golden(model, golden, name):
 
 
 def test_forward_vs_oracle_logits_and_late_queries(model, W):
-    clip = synth.make_clip(52, V=3, T=20, H=128, W=160, N=24, late_queries=True, query_frames=(3, 7, 13))
+    clip = synth.make_clip(57, V=3, T=20, H=128, W=160, N=24, late_queries=True, query_frames=(3, 7, 13))
     r = model(*args_of(clip, DEV), iters=4)
     ro = O.tracker_forward(W, CFG, *args_of(clip), iters=4, knn_mode="exact")
     assert model.last_windows == ro["windows"]
