@@ -1,22 +1,90 @@
 // Small-sequence attention for the updater (time attention over 12 frames, virtual<->point cross
 // attention over N tracks, virtual self attention over 64 tokens; cotracker2/blocks.py:258-271).
 //
-// One wave per (group, head, query).  Keys live on lanes: every lane scores its own key row
-// against the wave-uniform query (q in scalar registers), keeps a private online-softmax state
-// (m, l, acc[dh]) over its strided key subset, and the 64 partial states are merged once at the
-// end with shuffle reductions.  Strided row addressing (group stride / item stride in rows) lets
-// the same kernel walk the track-major token buffer along time or along tracks with no permute.
+// Two mappings, both walking the track-major token buffer through (group stride, item stride) row
+// addressing so that "along time" and "along tracks" need no permute:
+//   * nk <= 64  (time, virtual-self, point<-virtual): one LANE per (group, head, query).  The lane
+//     keeps q, the online-softmax state and the dh-wide accumulator in registers and streams the
+//     keys; lanes of a wave that share (group, head) read the same K/V rows (broadcast loads), and
+//     nothing is ever reduced across lanes.
+//   * nk > 64   (virtual<-point): one WAVE per (group, head, query), keys on lanes, each lane a private
+//     online-softmax state over its strided key subset; the 64 partial states are merged once through
+//     LDS (conflict-free [lane][dh+1] image, lane d sums column d).
 #include "common.h"
 
 namespace {
 
 template <int DH>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq, long long q_gs, long long q_is,
-                                                        const float* __restrict__ k, const float* __restrict__ v, int ldkv, long long k_gs,
-                                                        long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk,
-                                                        int heads) {
-  const int lane = threadIdx.x & 63;
-  const long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void attention_qlane_kernel(const float* __restrict__ q, int ldq, long long q_gs, long long q_is,
+                                                              const float* __restrict__ k, const float* __restrict__ v, int ldkv,
+                                                              long long k_gs, long long k_is, float* __restrict__ o, int ldo,
+                                                              int groups, int nq, int nk, int heads) {
+  const long long task = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ntask = (long long)groups * heads * nq;
+  if (task >= ntask) return;
+  const int qi = (int)(task % nq);
+  const int hd = (int)((task / nq) % heads);
+  const long long g = task / ((long long)nq * heads);
+  const long long qrow = g * q_gs + (long long)qi * q_is;
+  const float* qp = q + qrow * ldq + hd * DH;
+  const float scale = 1.0f / sqrtf((float)DH);
+  float qv[DH], acc[DH];
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(qp + d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qv[d + e] = t[e];
+      acc[d + e] = 0.f;
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  const float* kp = k + (g * k_gs) * ldkv + hd * DH;
+  const float* vp = v + (g * k_gs) * ldkv + hd * DH;
+  const long long kstep = k_is * ldkv;
+#pragma unroll 1
+  for (int j = 0; j < nk; ++j, kp += kstep, vp += kstep) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(kp + d);
+      s0 = fmaf(qv[d], t[0], s0);
+      s1 = fmaf(qv[d + 1], t[1], s1);
+      s2 = fmaf(qv[d + 2], t[2], s2);
+      s3 = fmaf(qv[d + 3], t[3], s3);
+    }
+    const float s = ((s0 + s1) + (s2 + s3)) * scale;
+    const float mn = fmaxf(m, s);
+    const float corr = expf(m - mn);
+    const float p = expf(s - mn);
+    l = l * corr + p;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(vp + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[d + e] = fmaf(p, t[e], acc[d + e] * corr);
+    }
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  float* op = o + qrow * ldo + hd * DH;
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = acc[d + e] * inv;
+    *reinterpret_cast<f32x4*>(op + d) = t;
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_klane_kernel(const float* __restrict__ q, int ldq, long long q_gs, long long q_is,
+                                                              const float* __restrict__ k, const float* __restrict__ v, int ldkv,
+                                                              long long k_gs, long long k_is, float* __restrict__ o, int ldo,
+                                                              int groups, int nq, int nk, int heads) {
+  __shared__ float red[4][64 * (DH + 1)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long task = (long long)blockIdx.x * 4 + wave;
   const long long ntask = (long long)groups * heads * nq;
   if (task >= ntask) return;
   const int qi = (int)(task % nq);
@@ -43,16 +111,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const long long krow = g * k_gs + (long long)j * k_is;
     const float* kp = k + krow * ldkv + hd * DH;
     const float* vp = v + krow * ldkv + hd * DH;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
       f32x4 t = *reinterpret_cast<const f32x4*>(kp + d);
-      s = fmaf(qv[d], t[0], s);
-      s = fmaf(qv[d + 1], t[1], s);
-      s = fmaf(qv[d + 2], t[2], s);
-      s = fmaf(qv[d + 3], t[3], s);
+      s0 = fmaf(qv[d], t[0], s0);
+      s1 = fmaf(qv[d + 1], t[1], s1);
+      s2 = fmaf(qv[d + 2], t[2], s2);
+      s3 = fmaf(qv[d + 3], t[3], s3);
     }
-    s *= scale;
+    const float s = ((s0 + s1) + (s2 + s3)) * scale;
     const float mn = fmaxf(m, s);
     const float corr = expf(m - mn);  // exp(-inf) = 0 on the first key
     const float p = expf(s - mn);
@@ -65,16 +133,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
     m = mn;
   }
-  // merge the 64 lane states
+  // merge the 64 lane states through LDS
   const float M = wave_max(m);
   const float w = (m == -INFINITY) ? 0.f : expf(m - M);
   const float L = wave_sum(l * w);
-  const float inv = 1.0f / L;
-  float* op = o + qrow * ldo + hd * DH;
+  float* r = red[wave];
 #pragma unroll
-  for (int d = 0; d < DH; ++d) {
-    const float r = wave_sum(acc[d] * w) * inv;
-    if (lane == (d & 63)) op[d] = r;
+  for (int d = 0; d < DH; ++d) r[lane * (DH + 1) + d] = acc[d] * w;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < DH) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) sum += r[i * (DH + 1) + lane];
+    o[qrow * ldo + hd * DH + lane] = sum / L;
   }
 }
 
@@ -84,18 +155,28 @@ extern "C" int mvt_attention(const float* q, int ldq, long long q_gs, long long 
                              long long k_gs, long long k_is, float* o, int ldo, int groups, int nq, int nk, int heads, int dh,
                              void* stream) {
   MVT_REQUIRE(q && k && v && o && groups > 0 && nq > 0 && nk > 0 && heads > 0);
-  MVT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldq >= heads * dh && ldkv >= heads * dh && ldo >= heads * dh);
-  MVT_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0));
+  MVT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= heads * dh && ldkv >= heads * dh && ldo >= heads * dh);
+  MVT_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 16 == 0));
   const long long ntask = (long long)groups * heads * nq;
-  const unsigned blocks = (unsigned)mvt_cdiv(ntask, 4);
-#define LAUNCH(DH)                                                                                                                \
-  hipLaunchKernelGGL((attention_kernel<DH>), dim3(blocks), dim3(256), 0, mvt_stream(stream), q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, \
+#define LAUNCH(KERN, DH, BLOCKS)                                                                                                 \
+  hipLaunchKernelGGL((KERN<DH>), dim3((unsigned)(BLOCKS)), dim3(256), 0, mvt_stream(stream), q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, \
                      o, ldo, groups, nq, nk, heads)
-  switch (dh) {
-    case 32: LAUNCH(32); break;
-    case 48: LAUNCH(48); break;
-    case 64: LAUNCH(64); break;
-    default: return MVT_ERR_ARG;
+  if (nk <= 64) {
+    const long long blocks = mvt_cdiv(ntask, 256);
+    switch (dh) {
+      case 32: LAUNCH(attention_qlane_kernel, 32, blocks); break;
+      case 48: LAUNCH(attention_qlane_kernel, 48, blocks); break;
+      case 64: LAUNCH(attention_qlane_kernel, 64, blocks); break;
+      default: return MVT_ERR_ARG;
+    }
+  } else {
+    const long long blocks = mvt_cdiv(ntask, 4);
+    switch (dh) {
+      case 32: LAUNCH(attention_klane_kernel, 32, blocks); break;
+      case 48: LAUNCH(attention_klane_kernel, 48, blocks); break;
+      case 64: LAUNCH(attention_klane_kernel, 64, blocks); break;
+      default: return MVT_ERR_ARG;
+    }
   }
 #undef LAUNCH
   return mvt_launch_status();

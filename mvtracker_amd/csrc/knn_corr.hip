@@ -39,6 +39,72 @@ __device__ __forceinline__ unsigned long long select_k(unsigned long long* list,
   return last;
 }
 
+// K-th smallest of the d2 bit patterns held two per lane (b0, b1; 0xFFFFFFFF = empty): radix select,
+// one ballot + scalar popcount per bit, no cross-lane data movement.  d2 >= 0, so bit 31 is clear.
+__device__ __forceinline__ unsigned kth_smallest_bits(unsigned b0, unsigned b1, int K) {
+  unsigned prefix = 0;
+  int need = K;
+  bool c0 = b0 != 0xFFFFFFFFu, c1 = b1 != 0xFFFFFFFFu;  // still matching the prefix
+#pragma unroll 1
+  for (int bit = 30; bit >= 0; --bit) {
+    const unsigned m = 1u << bit;
+    const bool z0 = c0 && !(b0 & m), z1 = c1 && !(b1 & m);
+    const int zeros = __popcll(__ballot(z0)) + __popcll(__ballot(z1));
+    if (zeros >= need) {  // the K-th smallest has this bit clear
+      c0 = z0;
+      c1 = z1;
+    } else {
+      need -= zeros;
+      prefix |= m;
+      c0 = c0 && (b0 & m);
+      c1 = c1 && (b1 & m);
+    }
+  }
+  return prefix;
+}
+
+// Shrink list[0..cnt) (cnt <= CAP) to the entries with d2 <= (K-th smallest d2); returns the new count
+// and that K-th smallest d2 through thr_bits.  Needs cnt >= K.
+__device__ __forceinline__ int tighten(unsigned long long* list, int cnt, int K, int lane, unsigned long long lt_mask,
+                                       unsigned* thr_bits) {
+  const unsigned long long e0 = lane < cnt ? list[lane] : KEY_MAX;
+  const unsigned long long e1 = 64 + lane < cnt ? list[64 + lane] : KEY_MAX;
+  const unsigned b0 = (unsigned)(e0 >> 32), b1 = (unsigned)(e1 >> 32);
+  const unsigned t = kth_smallest_bits(b0, b1, K);
+  const bool k0 = b0 <= t, k1 = b1 <= t && b1 != 0xFFFFFFFFu;
+  const unsigned long long m0 = __ballot(k0 && b0 != 0xFFFFFFFFu), m1 = __ballot(k1);
+  const int n0 = __popcll(m0);
+  __builtin_amdgcn_wave_barrier();
+  if (k0 && b0 != 0xFFFFFFFFu) list[__popcll(m0 & lt_mask)] = e0;
+  if (k1) list[n0 + __popcll(m1 & lt_mask)] = e1;
+  __builtin_amdgcn_wave_barrier();
+  *thr_bits = t;
+  return n0 + __popcll(m1);
+}
+
+// Sort list[0..cnt) (cnt <= 64) ascending by the full (d2, index) key and return, in lane r < K, the r-th key.
+__device__ __forceinline__ unsigned long long rank_sort(const unsigned long long* list, int cnt, int K, int lane) {
+  const unsigned long long e = lane < cnt ? list[lane] : KEY_MAX;
+  const unsigned lo = (unsigned)e, hi = (unsigned)(e >> 32);
+  int rank = 0;
+#pragma unroll 1
+  for (int j = 0; j < cnt; ++j) {
+    const unsigned long long ej = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+    rank += ej < e ? 1 : 0;
+  }
+  // lane r fetches the key whose rank is r: ranks are a permutation of 0..cnt-1 (keys are unique)
+  unsigned long long out = KEY_MAX;
+#pragma unroll 1
+  for (int j = 0; j < cnt; ++j) {
+    const int rj = __builtin_amdgcn_readlane(rank, j);
+    const unsigned long long ej = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+    if (rj == lane) out = ej;
+  }
+  return out;
+}
+
 template <int Q>
 __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ xyz, long long P, const float* __restrict__ coords,
                                                        int N, int S, int frame0, int frame_step, int T, int K, int nseg,
@@ -82,21 +148,33 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
     f32x4 pn = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (cn < c1) pn = *reinterpret_cast<const f32x4*>(cand + cn * 4);  // prefetch next step
     const bool live = c < c1;
+    float d2[Q];
+    unsigned long long m[Q];
+    unsigned long long any = 0;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
       const float dx = p[0] - qx[i], dy = p[1] - qy[i], dz = p[2] - qz[i];
-      const float d2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-      const bool pass = live && (d2 <= thr[i]);
-      const unsigned long long m = __ballot(pass);
-      if (m) {
-        unsigned long long* l = list + i * CAP;
-        if (pass) l[cnt[i] + __popcll(m & lt_mask)] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
-        cnt[i] += __popcll(m);
-        if (cnt[i] > CAP - 64) {
-          __builtin_amdgcn_wave_barrier();
-          unsigned long long kth = select_k(l, cnt[i], K, lane);
-          cnt[i] = K;
-          thr[i] = __uint_as_float((unsigned)(kth >> 32));
+      d2[i] = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+      m[i] = __ballot(live && (d2[i] <= thr[i]));
+      any |= m[i];
+    }
+    if (any) {  // rare after the warm-up: some query has a survivor in this step
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        if (m[i]) {
+          unsigned long long* l = list + i * CAP;
+          if ((m[i] >> lane) & 1ULL) l[cnt[i] + __popcll(m[i] & lt_mask)] = ((unsigned long long)__float_as_uint(d2[i]) << 32) | (unsigned)c;
+          cnt[i] += __popcll(m[i]);
+          if (cnt[i] > CAP - 64) {
+            unsigned tb;
+            int nc = tighten(l, cnt[i], K, lane, lt_mask, &tb);
+            if (nc > CAP - 64) {  // > 48 exact distance ties at the threshold: resolve them by index now
+              select_k(l, nc, K, lane);
+              nc = K;
+            }
+            cnt[i] = nc;
+            thr[i] = __uint_as_float(tb);
+          }
         }
       }
     }
@@ -108,11 +186,19 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
     const int n = qg * Q + i;
     unsigned long long* l = list + i * CAP;
     __builtin_amdgcn_wave_barrier();
-    select_k(l, cnt[i], K, lane);
-    if (n < N && lane < K) {
-      unsigned long long v = lane < cnt[i] ? l[lane] : KEY_MAX;
-      keys[(((long long)n * S + s) * nseg + seg) * K + lane] = v;
+    int nc = cnt[i];
+    if (nc > K) {
+      unsigned tb;
+      nc = tighten(l, nc, K, lane, lt_mask, &tb);
     }
+    unsigned long long v;
+    if (nc <= 64) {
+      v = rank_sort(l, nc, K, lane);
+    } else {
+      select_k(l, nc, K, lane);
+      v = lane < K ? l[lane] : KEY_MAX;
+    }
+    if (n < N && lane < K) keys[(((long long)n * S + s) * nseg + seg) * K + lane] = v;
   }
 }
 
