@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU")
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default=None,
+                    help="matrix-core arithmetic of convs/linears (default: the model's default)")
     ap.add_argument("--cpu-hw", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
@@ -96,6 +98,8 @@ def main():
     sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.to(dev)
+    if args.precision:
+        model.precision = args.precision
     V, T, HW, Nq = args.views, args.frames, args.size, args.queries
     clip = synth.make_clip(1234, V=V, T=T, H=HW, W=HW, N=Nq * world)  # same clip on every rank
     a = {k: torch.from_numpy(v).to(dev) for k, v in clip.items()}
@@ -153,7 +157,8 @@ def main():
         out = {
             "metric": "query-points*frames/sec, 4-view 24-frame 512x512 @1024 queries",
             "value": value, "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-precision bf16 MFMA, f32 accumulate, f32-grade)", "bf16": "bf16"}[model.precision],
             "data": "synthetic",
             "config": {"workload": f"{V}-view {T}-frame {HW}x{HW}, {Nq} queries per GPU, corr K=16 x 4 levels, iters={args.iters}, "
                                    f"3 windows, random-init weights (seeded recipe)",

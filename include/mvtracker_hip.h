@@ -60,14 +60,33 @@ int mvt_gemm(const float* A, int lda, const float* Wt, int ldw, const float* bia
 /* ---------------------------------------------------------------------------------------------
  * 2-D convolution as implicit GEMM on the matrix cores, channels-last.
  *   in  [n][H][W][Cin]   (Cin % 32 == 0, or Cin == 4 for the 7x7 stem with kw*4+c packing)
- *   wt  [Cout][KH][KW][Cin] repacked from torch's [Cout][Cin][KH][KW]; for the stem
- *       [Cout][KH][32] with element kw*4+c (c<3, kw<7) and zeros elsewhere
+ *   wt  [Cout][round_up(K,64)], row = [KH][KW][Cin] (K = KH*KW*Cin) repacked from torch's
+ *       [Cout][Cin][KH][KW] and zero padded; for the stem row = [KH][32] (K = KH*32) with element
+ *       kw*4+c (c<3, kw<7) and zeros elsewhere
  *   out [n][Ho][Wo][ldo] (ldo >= Cout; lets a conv write into a channel slice / the frame store)
  * Zero padding `pad`, stride `stride`.  Replaces nn.Conv2d in BasicEncoder / ResidualBlock
  * (mvtracker/models/core/spatracker/blocks.py:74-82, 116, 157-193).
  * --------------------------------------------------------------------------------------------- */
 int mvt_conv2d(const float* in, const float* wt, const float* bias, float* out, int n, int H, int W, int Cin,
                int Cout, int KH, int KW, int stride, int pad, int ldo, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * bf16 matrix-core variants of the two entry points above (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+ * Activations stay fp32 in memory and are converted while staged into LDS; weights are pre-split with
+ * mvt_split_bf16 into row-major bf16 [N][ldw], ldw = round_up(K,64), zero padded (conv: K = KH*KW*Cin in
+ * [kh][kw][cin] order, stem K = KH*32).
+ *   w_lo == NULL : plain bf16 operands (the arithmetic torch autocast gives the reference's convs/linears).
+ *   w_lo != NULL : split precision "bf16x3": x = hi + lo, products hi*hi + hi*lo + lo*hi -> fp32-grade
+ *                  results (dropped term 2^-16 relative) at 3/16 of the fp32-MFMA cost.
+ * --------------------------------------------------------------------------------------------- */
+/* hi[i] = bf16(src[i]) (round to nearest even), lo[i] = bf16(src[i] - hi[i]) (lo optional); n % 4 == 0. */
+int mvt_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, void* stream);
+int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const unsigned short* w_lo, int ldw,
+                  const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int act,
+                  void* stream);
+int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
+                    float* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
+                    int act, void* stream);
 
 /* rgbs [V][T][3][H][W] (values 0..255) -> x [T_sel][V][H][W][4] = (2*(rgb/255)-1, 0) for frames
  * t0..t0+nt-1 (mvtracker.py:565-567 normalisation + channels-last repack). */
@@ -120,9 +139,16 @@ int mvt_unproject(const float* depth_s, const float* kinv, const float* einv, fl
  * frame_of_slot = min(frame0 + s*frame_step, T-1) of xyz [T][P][4]; query = coords[(n*S+s)*3..].
  * d2 = fma(dz,dz,fma(dy,dy,dx*dx)), neighbours ascending by (d2, index).  The candidate range
  * is cut into nseg segments scanned by different waves; keys [N][S][nseg][K] receive
- * (d2 bits << 32 | index) per segment, ascending.  1 <= K <= 16, P >= K. */
+ * (d2 bits << 32 | index) per segment, ascending (KEY_MAX = ~0 pads a segment that holds fewer than K
+ * survivors of a seeded scan).  1 <= K <= 16, P >= K.
+ * Optional pruning seed (exactness preserved): seed_idx [N][S][seed_k] int32, seed_k >= K distinct point
+ * indices per (query, slot) -- e.g. the previous iteration's neighbours (seed_cw == 0), or the neighbours found
+ * on the next coarser pyramid level (seed_cw, seed_ch = coarse per-view grid; seed_fw, seed_fh = this level's
+ * per-view grid; coarse (v,y,x) maps to (v,2y,2x)).  The scan then starts from the bound
+ * max_j d2(query, seed_j) >= (K-th nearest distance) instead of +inf. */
 int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step,
-                 int T, int K, int nseg, unsigned long long* keys, void* stream);
+                 int T, int K, int nseg, unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw,
+                 int seed_ch, int seed_fw, int seed_fh, void* stream);
 /* Gather-dot for one pyramid level: merges the nseg partial lists of mvt_knn_scan, gathers the
  * K neighbour rows of fvec [T][P][C] (C % 4 == 0, C <= 256, groups == 1) and writes, for
  * k < K:  out[(n*S+s)*ldo + o_off + 4k + {0,1,2,3}] = { <target, f_k>/sqrt(C), xyz_k - coord }

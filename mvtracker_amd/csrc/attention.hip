@@ -149,6 +149,107 @@ __global__ __launch_bounds__(256) void attention_klane_kernel(const float* __res
   }
 }
 
+// Queries on lanes, keys wave-uniform: a wave owns 64 consecutive queries of one (group, head); every key / value
+// row is the same for all lanes, so it is fetched with scalar loads and feeds the FMAs from SGPRs (no LDS, no
+// per-lane K/V traffic).  KS > 1 splits the keys of one query chunk over KS waves whose online-softmax states are
+// merged through LDS (virtual<-point attention: 64 queries x 1024 keys).
+template <int DH, int KS>
+__global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_ukeys_kernel(
+    const float* __restrict__ q, int ldq, long long q_gs, long long q_is, const float* __restrict__ k, const float* __restrict__ v,
+    int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads) {
+  __shared__ float red[(KS > 1 ? (KS - 1) * 64 * (DH + 2) : 1)];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunks = (nq + 63) / 64;
+  const long long nchunk = (long long)groups * heads * chunks;
+  const long long chunk_id = KS == 1 ? (long long)blockIdx.x * 4 + wave : (long long)blockIdx.x;
+  const bool chunk_ok = chunk_id < nchunk;  // KS == 1 only: trailing waves of the last block
+  const long long cid = chunk_ok ? chunk_id : 0;
+  const int qc = (int)(cid % chunks);
+  const int hd = (int)((cid / chunks) % heads);
+  const long long g = cid / ((long long)chunks * heads);
+  const int qi = qc * 64 + lane;
+  const bool active = chunk_ok && qi < nq;
+  const long long qrow = g * q_gs + (long long)(active ? qi : 0) * q_is;
+  const float* qp = q + qrow * ldq + hd * DH;
+  const float scale = 1.0f / sqrtf((float)DH);
+  float qv[DH], acc[DH];
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(qp + d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qv[d + e] = t[e] * scale;
+      acc[d + e] = 0.f;
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  const int per = (nk + KS - 1) / KS;
+  const int j0 = KS == 1 ? 0 : wave * per;
+  const int j1 = KS == 1 ? nk : (j0 + per < nk ? j0 + per : nk);
+  const float* kp = k + (g * k_gs + (long long)j0 * k_is) * ldkv + hd * DH;
+  const float* vp = v + (g * k_gs + (long long)j0 * k_is) * ldkv + hd * DH;
+  const long long kstep = k_is * ldkv;
+#pragma unroll 1
+  for (int j = j0; j < j1; ++j, kp += kstep, vp += kstep) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+      s0 = fmaf(qv[d], kp[d], s0);
+      s1 = fmaf(qv[d + 1], kp[d + 1], s1);
+      s2 = fmaf(qv[d + 2], kp[d + 2], s2);
+      s3 = fmaf(qv[d + 3], kp[d + 3], s3);
+    }
+    const float s = (s0 + s1) + (s2 + s3);
+    if (__ballot(s > m)) {  // some lane has a new running maximum: rescale (rare after the first keys)
+      const float mn = fmaxf(m, s);
+      const float corr = expf(m - mn);
+      l *= corr;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) acc[d] *= corr;
+      m = mn;
+    }
+    const float p = expf(s - m);
+    l += p;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] = fmaf(p, vp[d], acc[d]);
+  }
+  if (KS > 1) {
+    if (wave > 0) {
+      float* r = red + ((wave - 1) * 64 + lane) * (DH + 2);
+      r[0] = m;
+      r[1] = l;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) r[2 + d] = acc[d];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll 1
+    for (int w = 0; w < KS - 1; ++w) {
+      const float* r = red + (w * 64 + lane) * (DH + 2);
+      const float mw = r[0];
+      const float mn = fmaxf(m, mw);
+      const float ca = (m == -INFINITY) ? 0.f : expf(m - mn);
+      const float cb = (mw == -INFINITY) ? 0.f : expf(mw - mn);
+      l = l * ca + r[1] * cb;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) acc[d] = acc[d] * ca + r[2 + d] * cb;
+      m = mn;
+    }
+  }
+  if (active) {
+    const float inv = 1.0f / l;
+    float* op = o + qrow * ldo + hd * DH;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4) {
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = acc[d + e] * inv;
+      *reinterpret_cast<f32x4*>(op + d) = t;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mvt_attention(const float* q, int ldq, long long q_gs, long long q_is, const float* k, const float* v, int ldkv,
@@ -161,7 +262,29 @@ extern "C" int mvt_attention(const float* q, int ldq, long long q_gs, long long 
 #define LAUNCH(KERN, DH, BLOCKS)                                                                                                 \
   hipLaunchKernelGGL((KERN<DH>), dim3((unsigned)(BLOCKS)), dim3(256), 0, mvt_stream(stream), q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, \
                      o, ldo, groups, nq, nk, heads)
-  if (nk <= 64) {
+  if (nq >= 64) {  // queries on lanes, keys wave-uniform
+    const long long nchunk = (long long)groups * heads * ((nq + 63) / 64);
+#define LAUNCH_U(DH, KS, BLOCKS, THREADS)                                                                                        \
+  hipLaunchKernelGGL((attention_ukeys_kernel<DH, KS>), dim3((unsigned)(BLOCKS)), dim3(THREADS), 0, mvt_stream(stream), q, ldq, q_gs, \
+                     q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads)
+    if (nk > 64) {
+      switch (dh) {
+        case 32: LAUNCH_U(32, 8, nchunk, 512); break;
+        case 48: LAUNCH_U(48, 8, nchunk, 512); break;
+        case 64: LAUNCH_U(64, 8, nchunk, 512); break;
+        default: return MVT_ERR_ARG;
+      }
+    } else {
+      const long long blocks = mvt_cdiv(nchunk, 4);
+      switch (dh) {
+        case 32: LAUNCH_U(32, 1, blocks, 256); break;
+        case 48: LAUNCH_U(48, 1, blocks, 256); break;
+        case 64: LAUNCH_U(64, 1, blocks, 256); break;
+        default: return MVT_ERR_ARG;
+      }
+    }
+#undef LAUNCH_U
+  } else if (nk <= 64) {
     const long long blocks = mvt_cdiv(ntask, 256);
     switch (dh) {
       case 32: LAUNCH(attention_qlane_kernel, 32, blocks); break;

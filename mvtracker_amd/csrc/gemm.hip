@@ -28,7 +28,9 @@ struct GemmArgs {
   int act;
   int mode;  // 0 dense, 1 conv (Cin % 32 == 0), 2 stem (Cin == 4)
   int H, Wd, Cin, Ho, Wo, KH, KW, stride, pad;
-  int nk;  // number of 32-wide k tiles
+  int nk;  // number of k tiles (32 wide for the fp32 kernel, 64 wide for the bf16 kernels)
+  const unsigned short* Whi;  // bf16 kernels: weights pre-split into bf16 hi (+ lo for the split-precision mode)
+  const unsigned short* Wlo;
 };
 
 constexpr int BK = 32;
@@ -194,14 +196,260 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(GemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 matrix-core path.  v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate.  Two modes:
+//   SPLIT = false : operands rounded to bf16, fp32 accumulate (what torch autocast does to the
+//                   reference's convs / linears).
+//   SPLIT = true  : "bf16x3": every fp32 operand x is split as hi = bf16(x), lo = bf16(x - hi) and the
+//                   product is accumulated as hi*hi + hi*lo + lo*hi in fp32 (the dropped lo*lo term is
+//                   2^-16 relative): fp32-grade results at 3 bf16 MFMAs instead of 8 fp32 MFMAs per k=16.
+// Activations are converted while they are staged into LDS; weights are pre-split once on the host side
+// (mvt_split_bf16).  k-tile = 64; LDS rows are 64+8 bf16 (144 B: conflict-free ds_read_b128, 8-byte aligned
+// ds_write_b64); lane (r, h) reads the 8 consecutive k of its half for each 16-wide MFMA step.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BKB = 64;
+constexpr int LDB = BKB + 8;  // bf16 elements per LDS row
+
+__device__ __forceinline__ void split4(const f32x4& v, uint2& hi, uint2& lo) {
+  bf16x4 h = __builtin_convertvector(v, bf16x4);
+  f32x4 hf = __builtin_convertvector(h, f32x4);
+  bf16x4 l = __builtin_convertvector(v - hf, bf16x4);
+  hi = __builtin_bit_cast(uint2, h);
+  lo = __builtin_bit_cast(uint2, l);
+}
+
+template <int TM, int TN, int WM, int WN, bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int AF = BM / 16;  // float4 (A) / 4xbf16 (W) per thread per k-tile
+  constexpr int BF = BN / 16;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  __shared__ __attribute__((aligned(16))) unsigned short lds[(BM + BN) * LDB * (SPLIT ? 2 : 1)];
+  unsigned short* Ah = lds;
+  unsigned short* Bh = Ah + BM * LDB;
+  unsigned short* Al = Bh + BN * LDB;
+  unsigned short* Bl = Al + (SPLIT ? BM * LDB : 0);
+
+  const int t = threadIdx.x;
+  const int c4 = t & 15;
+  const int rbase = t >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x % tiles_n;
+  const long long m0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const float* a_ptr[AF];
+  unsigned a_hw[AF];
+#pragma unroll
+  for (int i = 0; i < AF; ++i) {
+    long long m = m0 + rbase + 16 * i;
+    bool ok = m < p.M;
+    if (p.mode == 0) {
+      a_ptr[i] = p.A + (ok ? m : 0) * (long long)p.lda + c4 * 4;
+      a_hw[i] = ok ? 1 : 0;
+    } else {
+      long long hw = (long long)p.Ho * p.Wo;
+      long long img = ok ? m / hw : 0;
+      int rem = ok ? (int)(m - img * hw) : 0;
+      int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+      int ih0 = ok ? oh * p.stride - p.pad : -20000;
+      int iw0 = ow * p.stride - p.pad;
+      a_ptr[i] = p.A + img * (long long)p.H * p.Wd * p.Cin;
+      a_hw[i] = ((unsigned)(ih0 + 32000) << 16) | (unsigned)(iw0 + 64);
+    }
+  }
+  long long w_off[BF];
+  bool w_ok[BF];
+#pragma unroll
+  for (int i = 0; i < BF; ++i) {
+    int n = n0 + rbase + 16 * i;
+    w_ok[i] = n < p.N;
+    w_off[i] = (long long)(w_ok[i] ? n : 0) * p.ldw + c4 * 4;
+  }
+  const int kp4 = (p.K + 3) & ~3;
+
+  f32x4 ra[AF];
+  uint2 rbh[BF], rbl[BF];
+  auto load_tile = [&](int kt) {
+    const int k = kt * BKB + c4 * 4;
+    if (p.mode == 0) {
+      const bool kok = k < kp4;
+#pragma unroll
+      for (int i = 0; i < AF; ++i) {
+        ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kok && a_hw[i]) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BKB);
+      }
+    } else if (p.mode == 1) {
+      const int tap = k / p.Cin;
+      const int c = k - tap * p.Cin;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const bool kok = k < p.K;
+#pragma unroll
+      for (int i = 0; i < AF; ++i) {
+        int ih = (int)(a_hw[i] >> 16) - 32000 + kh;
+        int iw = (int)(a_hw[i] & 0xFFFFu) - 64 + kw;
+        ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
+          ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((long long)ih * p.Wd + iw) * p.Cin + c);
+      }
+    } else {
+      const int kh = k >> 5, kw = (k & 31) >> 2;
+      const bool kok = kh < p.KH && kw < p.KW;
+#pragma unroll
+      for (int i = 0; i < AF; ++i) {
+        int ih = (int)(a_hw[i] >> 16) - 32000 + kh;
+        int iw = (int)(a_hw[i] & 0xFFFFu) - 64 + kw;
+        ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
+          ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((long long)ih * p.Wd + iw) * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BF; ++i) {
+      rbh[i] = make_uint2(0u, 0u);
+      rbl[i] = make_uint2(0u, 0u);
+      if (w_ok[i]) {
+        rbh[i] = *reinterpret_cast<const uint2*>(p.Whi + w_off[i] + kt * BKB);
+        if (SPLIT) rbl[i] = *reinterpret_cast<const uint2*>(p.Wlo + w_off[i] + kt * BKB);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AF; ++i) {
+      uint2 hi, lo;
+      split4(ra[i], hi, lo);
+      const int o = (rbase + 16 * i) * LDB + c4 * 4;
+      *reinterpret_cast<uint2*>(&Ah[o]) = hi;
+      if (SPLIT) *reinterpret_cast<uint2*>(&Al[o]) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < BF; ++i) {
+      const int o = (rbase + 16 * i) * LDB + c4 * 4;
+      *reinterpret_cast<uint2*>(&Bh[o]) = rbh[i];
+      if (SPLIT) *reinterpret_cast<uint2*>(&Bl[o]) = rbl[i];
+    }
+  };
+
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const bool more = kt + 1 < p.nk;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BKB / 16; ++ks) {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = ((wm * TM + i) * 32 + r) * LDB + ks * 16 + h * 8;
+        ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Ah[o]));
+        if (SPLIT) al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Al[o]));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = ((wn * TN + j) * 32 + r) * LDB + ks * 16 + h * 8;
+        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bh[o]));
+        if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Bl[o]));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (SPLIT) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (more) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + r;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        long long m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < p.M) {
+          float v = mvt_act(acc[i][j][e] + bv, p.act);
+          if (p.R) v += p.R[m * p.ldr + n];
+          p.C[m * p.ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+inline int pick_tile(const GemmArgs& a);
+
+template <bool SPLIT>
+int launch_gemm_bf16(const GemmArgs& a, hipStream_t s) {
+  auto blocks = [&](int bm, int bn) { return (unsigned)(mvt_cdiv(a.M, bm) * mvt_cdiv(a.N, bn)); };
+  switch (pick_tile(a)) {
+    case 1: hipLaunchKernelGGL((gemm_mfma_bf16<1, 3, 4, 1, SPLIT>), dim3(blocks(128, 96)), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((gemm_mfma_bf16<2, 2, 4, 1, SPLIT>), dim3(blocks(256, 64)), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((gemm_mfma_bf16<1, 2, 2, 2, SPLIT>), dim3(blocks(64, 128)), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((gemm_mfma_bf16<1, 1, 2, 2, SPLIT>), dim3(blocks(64, 64)), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((gemm_mfma_bf16<2, 2, 2, 2, SPLIT>), dim3(blocks(128, 128)), dim3(256), 0, s, a); break;
+  }
+  return mvt_launch_status();
+}
+
+__global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                  long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    uint2 h, l;
+    split4(*reinterpret_cast<const f32x4*>(src + i * 4), h, l);
+    *reinterpret_cast<uint2*>(hi + i * 4) = h;
+    if (lo) *reinterpret_cast<uint2*>(lo + i * 4) = l;
+  }
+}
+
+// Tile choice: the largest tile that still gives every CU at least two workgroups (latency hiding comes from
+// co-resident blocks); narrow N picks the matching BN so no MFMA columns are wasted.
+inline int pick_tile(const GemmArgs& a) {
+  auto nb = [&](int bm, int bn) { return mvt_cdiv(a.M, bm) * mvt_cdiv(a.N, bn); };
+  if (a.N % 128 != 0 && a.N % 96 == 0) return 1;          // 128 x 96
+  if (a.N <= 64) return nb(256, 64) >= 512 ? 2 : 4;      // 256 x 64, else 64 x 64
+  if (nb(128, 128) >= 512) return 0;                      // 128 x 128
+  if (nb(64, 128) >= 512) return 3;                       // 64 x 128
+  return 4;                                               // 64 x 64
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
   auto blocks = [&](int bm, int bn) { return (unsigned)(mvt_cdiv(a.M, bm) * mvt_cdiv(a.N, bn)); };
-  if (a.N % 128 != 0 && a.N % 96 == 0) {
-    hipLaunchKernelGGL((gemm_mfma_f32<1, 3, 4, 1>), dim3(blocks(128, 96)), dim3(256), 0, s, a);
-  } else if (a.N <= 64) {
-    hipLaunchKernelGGL((gemm_mfma_f32<2, 2, 4, 1>), dim3(blocks(256, 64)), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((gemm_mfma_f32<2, 2, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, s, a);
+  switch (pick_tile(a)) {
+    case 1: hipLaunchKernelGGL((gemm_mfma_f32<1, 3, 4, 1>), dim3(blocks(128, 96)), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((gemm_mfma_f32<2, 2, 4, 1>), dim3(blocks(256, 64)), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((gemm_mfma_f32<1, 2, 2, 2>), dim3(blocks(64, 128)), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((gemm_mfma_f32<1, 1, 2, 2>), dim3(blocks(64, 64)), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((gemm_mfma_f32<2, 2, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, s, a); break;
   }
   return mvt_launch_status();
 }
@@ -240,10 +488,63 @@ extern "C" int mvt_conv2d(const float* in, const float* wt, const float* bias, f
   a.M = (int)M; a.N = Cout; a.ldc = ldo; a.ldr = 0; a.act = act;
   a.H = H; a.Wd = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   if (Cin == 4) {
-    a.mode = 2; a.nk = KH; a.K = KH * 32; a.ldw = KH * 32;
+    a.mode = 2; a.nk = KH; a.K = KH * 32;
   } else {
-    a.mode = 1; a.K = KH * KW * Cin; a.nk = a.K / BK; a.ldw = a.K;
+    a.mode = 1; a.K = KH * KW * Cin; a.nk = a.K / BK;
   }
+  a.ldw = (a.K + 63) & ~63;  // weights are [Cout][round_up(K, 64)], zero padded
   a.lda = 0;
   return launch_gemm(a, mvt_stream(stream));
+}
+
+extern "C" int mvt_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, void* stream) {
+  MVT_REQUIRE(src && hi && n > 0 && n % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)hi % 8 == 0));
+  long long n4 = n / 4;
+  long long g = mvt_cdiv(n4, 256);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, mvt_stream(stream), src, hi, lo, n4);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_gemm_bf16(const float* A, int lda, const unsigned short* Whi, const unsigned short* Wlo, int ldw,
+                             const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int act,
+                             void* stream) {
+  MVT_REQUIRE(A && Whi && C && M > 0 && N > 0 && K > 0);
+  MVT_REQUIRE(lda % 4 == 0 && lda >= ((K + 3) & ~3));
+  MVT_REQUIRE(ldw % 64 == 0 && ldw >= ((K + 63) & ~63) && ldc >= N && (!R || ldr >= N));
+  MVT_REQUIRE(act >= 0 && act <= 3);
+  MVT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)Whi % 8 == 0) && ((uintptr_t)Wlo % 8 == 0));
+  GemmArgs a{};
+  a.A = A; a.Whi = Whi; a.Wlo = Wlo; a.bias = bias; a.R = R; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.act = act;
+  a.mode = 0;
+  a.nk = (K + BKB - 1) / BKB;
+  return Wlo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));
+}
+
+extern "C" int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
+                               float* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
+                               int act, void* stream) {
+  MVT_REQUIRE(in && wt_hi && out && n > 0 && H > 0 && W > 0 && Cout > 0);
+  MVT_REQUIRE(KH >= 1 && KH <= 7 && KW >= 1 && KW <= 7 && stride >= 1 && stride <= 2 && pad >= 0 && pad <= 3);
+  MVT_REQUIRE(H < 16384 && W < 16384 && ldo >= Cout && act >= 0 && act <= 3);
+  MVT_REQUIRE((Cin % 32 == 0) || (Cin == 4));
+  MVT_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)wt_hi % 8 == 0) && ((uintptr_t)wt_lo % 8 == 0));
+  const int Ho = (H + 2 * pad - KH) / stride + 1;
+  const int Wo = (W + 2 * pad - KW) / stride + 1;
+  MVT_REQUIRE(Ho > 0 && Wo > 0);
+  const long long M = (long long)n * Ho * Wo;
+  MVT_REQUIRE(M < (1LL << 31));
+  GemmArgs a{};
+  a.A = in; a.Whi = wt_hi; a.Wlo = wt_lo; a.bias = bias; a.R = nullptr; a.C = out;
+  a.M = (int)M; a.N = Cout; a.ldc = ldo; a.ldr = 0; a.act = act;
+  a.H = H; a.Wd = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  if (Cin == 4) {
+    a.mode = 2; a.K = KH * 32;
+  } else {
+    a.mode = 1; a.K = KH * KW * Cin;
+  }
+  a.nk = (a.K + BKB - 1) / BKB;
+  a.ldw = a.nk * BKB;  // weights are [Cout][round_up(K, 64)], zero padded
+  a.lda = 0;
+  return wt_lo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));
 }

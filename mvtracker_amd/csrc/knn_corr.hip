@@ -108,7 +108,9 @@ __device__ __forceinline__ unsigned long long rank_sort(const unsigned long long
 template <int Q>
 __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ xyz, long long P, const float* __restrict__ coords,
                                                        int N, int S, int frame0, int frame_step, int T, int K, int nseg,
-                                                       unsigned long long* __restrict__ keys, int qgroups) {
+                                                       unsigned long long* __restrict__ keys, int qgroups,
+                                                       const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch,
+                                                       int seed_fw, int seed_fh) {
   __shared__ unsigned long long lds[4 * Q * CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // task id -> (segment, query group, slot); segment fastest so that heavy frames spread over CUs
@@ -137,17 +139,38 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
     qz[i] = uniform_f(c[2]);
     thr[i] = __int_as_float(0x7f800000);  // +inf
     cnt[i] = 0;
+    if (seed_idx) {
+      // Any seed_k >= K distinct points of this frame bound the K-th nearest distance from above: start with
+      // thr = max d2 over the seeds (the previous iteration's neighbours, or the coarser level's neighbours mapped
+      // to this level's grid), so that almost no candidate survives the compare.  Exactness is unaffected.
+      float d2s = 0.f;
+      if (lane < seed_k) {
+        int si = seed_idx[((long long)(n < N ? n : N - 1) * S + s) * seed_k + lane];
+        if (seed_cw > 0) {  // coarse (v, y, x) -> fine (v, 2y, 2x)
+          const int pv = seed_cw * seed_ch;
+          const int v = si / pv, rem = si - v * pv;
+          const int y = rem / seed_cw, x = rem - y * seed_cw;
+          si = (v * seed_fh + 2 * y) * seed_fw + 2 * x;
+        }
+        si = si < 0 ? 0 : (si < P ? si : (int)(P - 1));
+        const f32x4 sp = *reinterpret_cast<const f32x4*>(cand + (long long)si * 4);
+        const float dx = sp[0] - qx[i], dy = sp[1] - qy[i], dz = sp[2] - qz[i];
+        d2s = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+        if (!(d2s == d2s)) d2s = __int_as_float(0x7f800000);  // NaN coordinates: no bound
+      }
+      thr[i] = uniform_f(wave_max(d2s));
+    }
   }
   const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
 
   long long c = c0 + lane;
-  f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float qnan = __int_as_float(0x7fc00000);  // lanes past the segment end carry NaN points: every compare fails
+  f32x4 p = (f32x4){qnan, qnan, qnan, 0.f};
   if (c < c1) p = *reinterpret_cast<const f32x4*>(cand + c * 4);
   for (long long base = c0; base < c1; base += 64) {
     const long long cn = base + 64 + lane;
-    f32x4 pn = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 pn = (f32x4){qnan, qnan, qnan, 0.f};
     if (cn < c1) pn = *reinterpret_cast<const f32x4*>(cand + cn * 4);  // prefetch next step
-    const bool live = c < c1;
     float d2[Q];
     unsigned long long m[Q];
     unsigned long long any = 0;
@@ -155,7 +178,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
     for (int i = 0; i < Q; ++i) {
       const float dx = p[0] - qx[i], dy = p[1] - qy[i], dz = p[2] - qz[i];
       d2[i] = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-      m[i] = __ballot(live && (d2[i] <= thr[i]));
+      m[i] = __ballot(d2[i] <= thr[i]);
       any |= m[i];
     }
     if (any) {  // rare after the warm-up: some query has a survivor in this step
@@ -346,7 +369,10 @@ __global__ __launch_bounds__(256) void window_corr_kernel(const float* __restric
 }  // namespace
 
 extern "C" int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step, int T,
-                            int K, int nseg, unsigned long long* keys, void* stream) {
+                            int K, int nseg, unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw, int seed_ch,
+                            int seed_fw, int seed_fh, void* stream) {
+  MVT_REQUIRE(!seed_idx || (seed_k >= K && seed_k <= 64 && seed_cw >= 0));
+  MVT_REQUIRE(!seed_idx || seed_cw == 0 || (seed_ch > 0 && seed_fw >= 2 * seed_cw && seed_fh >= 2 * seed_ch));
   MVT_REQUIRE(xyz && coords && keys && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0);
   MVT_REQUIRE(K >= 1 && K <= 16 && nseg >= 1 && nseg * K <= 64 && P < (1LL << 31));
   MVT_REQUIRE((P + nseg - 1) / nseg >= K && ((P + nseg - 1) / nseg) * (nseg - 1) + K <= P);  // every segment holds >= K points
@@ -354,7 +380,7 @@ extern "C" int mvt_knn_scan(const float* xyz, long long P, const float* coords, 
   const int qgroups = (N + Q - 1) / Q;
   const long long ntask = (long long)qgroups * S * nseg;
   hipLaunchKernelGGL((knn_scan_kernel<Q>), dim3((unsigned)mvt_cdiv(ntask, 4)), dim3(256), 0, mvt_stream(stream), xyz, P, coords, N, S,
-                     frame0, frame_step, T, K, nseg, keys, qgroups);
+                     frame0, frame_step, T, K, nseg, keys, qgroups, seed_idx, seed_k, seed_cw, seed_ch, seed_fw, seed_fh);
   return mvt_launch_status();
 }
 

@@ -29,6 +29,9 @@ SIGNATURES = {
     "mvt_build_arch": [],
     "mvt_gemm": [P, I, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "mvt_split_bf16": [P, P, P, LL, P],
+    "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, P],
+    "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
     "mvt_instnorm_stats": [P, I, P, P, I, LL, I, P],
@@ -38,7 +41,7 @@ SIGNATURES = {
     "mvt_depth_subsample": [P, P, I, I, I, I, I, P],
     "mvt_avgpool2": [P, P, LL, I, I, I, P],
     "mvt_unproject": [P, P, P, P, I, I, I, I, I, I, P],
-    "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P],
+    "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P],
     "mvt_corr_gather_dot": [P, P, LL, I, P, P, P, I, I, I, I, I, I, I, P, I, I, P, P],
     "mvt_knn1_gather": [P, LL, I, P, I, I, I, P, P, P],
     "mvt_window_corr": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
@@ -111,6 +114,20 @@ def conv2d(x, wt, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=A
     _call("mvt_conv2d", _ptr(x), _ptr(wt), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act, _stream())
 
 
+def split_bf16(src, hi, lo, n):
+    _call("mvt_split_bf16", _ptr(src), _ptr(hi), _ptr(lo), n, _stream())
+
+
+def gemm_bf16(A, lda, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NONE):
+    _call("mvt_gemm_bf16", _ptr(A), lda, _ptr(Whi), _ptr(Wlo), ldw, _ptr(bias), _ptr(R), ldr, _ptr(Cm), ldc, M, N, K, act,
+          _stream())
+
+
+def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE):
+    _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
+          ldo, act, _stream())
+
+
 def rgb_to_nhwc4(rgbs, out, V, T, H, W, t0, nt):
     _call("mvt_rgb_to_nhwc4", _ptr(_f32c(rgbs)), _ptr(out), V, T, H, W, t0, nt, _stream())
 
@@ -147,8 +164,10 @@ def unproject(depth_s, kinv, einv, xyz, V, T, hs, ws, stride, level):
     _call("mvt_unproject", _ptr(depth_s), _ptr(kinv), _ptr(einv), _ptr(xyz), V, T, hs, ws, stride, level, _stream())
 
 
-def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys):
-    _call("mvt_knn_scan", _ptr(xyz), Pn, _ptr(coords), N, S, frame0, frame_step, T, K, nseg, _ptr(keys), _stream())
+def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_idx=None, seed_k=0, seed_dims=(0, 0, 0, 0)):
+    """seed_dims = (coarse_w, coarse_h, fine_w, fine_h) per-view grids when the seed comes from the coarser level."""
+    _call("mvt_knn_scan", _ptr(xyz), Pn, _ptr(coords), N, S, frame0, frame_step, T, K, nseg, _ptr(keys), _ptr(seed_idx), seed_k,
+          *seed_dims, _stream())
 
 
 def corr_gather_dot(xyz, fvec, Pn, Cc, targets, coords, keys, N, S, frame0, frame_step, T, K, nseg, out, ldo, o_off,

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -98,6 +99,11 @@ class MVTracker(nn.Module):
             _insert(self, key, self._init_tensor(key, shape))
         self._packed: Optional[dict] = None
         self._packed_sig = None
+        # arithmetic of the matrix-core kernels (convs + linears); everything else is always fp32:
+        #   "fp32"   v_mfma_f32_32x32x2_f32, exact fp32 FMA chains
+        #   "bf16x3" split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi), fp32-grade results, ~5x the fp32 MFMA rate
+        #   "bf16"   operands rounded to bf16, fp32 accumulate (the arithmetic of torch autocast in the reference demo)
+        self.precision = os.environ.get("MVT_PRECISION", "fp32")
         d = self.updateformer_input_dim
         self._time_embed_host = self._make_time_embed(self.S, d)
 
@@ -183,7 +189,8 @@ class MVTracker(nn.Module):
 
     # ------------------------------------------------------------------ weight packing for the kernels
     def _signature(self, dev):
-        return (str(dev),) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        assert self.precision in ("fp32", "bf16x3", "bf16"), self.precision
+        return (str(dev), self.precision) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
     def _pack(self, dev) -> dict:
         sig = self._signature(dev)
@@ -192,22 +199,35 @@ class MVTracker(nn.Module):
         sd = {k: v.detach().to(device=dev, dtype=torch.float32) for k, v in self.state_dict().items()}
         pk: dict = {}
 
+        prec = self.precision
+
+        def matrix(w2d):
+            """[N][K] fp32 -> zero-padded [N][round_up(K,64)] in the layout of the selected precision:
+            fp32 tensor, or (bf16 hi, bf16 lo | None) as int16 tensors."""
+            n, k = w2d.shape
+            wp = torch.zeros(n, _round_up(k, 64), device=dev)
+            wp[:, :k] = w2d
+            if prec == "fp32":
+                return wp
+            hi = torch.empty(wp.shape, device=dev, dtype=torch.int16)
+            lo = torch.empty(wp.shape, device=dev, dtype=torch.int16) if prec == "bf16x3" else None
+            hip.split_bf16(wp, hi, lo, wp.numel())
+            return (hi, lo)
+
         def conv(name):
             w = sd[name + ".weight"]
-            pk[name] = (w.permute(0, 2, 3, 1).contiguous(), sd[name + ".bias"].contiguous())
+            pk[name] = (matrix(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)), sd[name + ".bias"].contiguous())
 
         def lin(name, w=None, b=None):
             w = sd[name + ".weight"] if w is None else w
             b = sd[name + ".bias"] if b is None else b
             n, k = w.shape
-            wp = torch.zeros(n, _round_up(k, 32), device=dev)
-            wp[:, :k] = w
-            pk[name] = (wp, b.contiguous(), n, k)
+            pk[name] = (matrix(w), b.contiguous(), n, k)
 
         w = sd["fnet.conv1.weight"]  # (64,3,7,7) -> [64][7][32] with element kw*4+c
         st = torch.zeros(64, 7, 8, 4, device=dev)
         st[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-        pk["fnet.conv1"] = (st.reshape(64, 7 * 32).contiguous(), sd["fnet.conv1.bias"].contiguous())
+        pk["fnet.conv1"] = (matrix(st.reshape(64, 7 * 32)), sd["fnet.conv1.bias"].contiguous())
         for k in sd:
             if k.startswith("fnet.") and k.endswith(".weight") and k != "fnet.conv1.weight":
                 conv(k[:-7])
@@ -243,7 +263,10 @@ class MVTracker(nn.Module):
         if out is None:
             out = torch.empty(n, Ho, Wo, cout, device=x.device)
             ldo = cout
-        hip.conv2d(x, wt, b, out, n, H, W, cin, cout, k, k, stride, pad, ldo)
+        if isinstance(wt, tuple):
+            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo)
+        else:
+            hip.conv2d(x, wt, b, out, n, H, W, cin, cout, k, k, stride, pad, ldo)
         return out, Ho, Wo
 
     def _inorm(self, x, n, HW, C, skip=None, skip_stats=None, apply=True):
@@ -336,7 +359,10 @@ class MVTracker(nn.Module):
     # ------------------------------------------------------------------ updater (cotracker2/blocks.py:455-494)
     def _lin(self, pk, name, A, lda, M, out, ldc, act=hip.ACT_NONE, R=None, ldr=0):
         wp, b, n, k = pk[name]
-        hip.gemm(A, lda, wp, wp.shape[1], b, R, ldr, out, ldc, M, n, k, act)
+        if isinstance(wp, tuple):
+            hip.gemm_bf16(A, lda, wp[0], wp[1], wp[0].shape[1], b, R, ldr, out, ldc, M, n, k, act)
+        else:
+            hip.gemm(A, lda, wp, wp.shape[1], b, R, ldr, out, ldc, M, n, k, act)
 
     def _mlp_residual(self, pk, p, tok, rows, xn, hbuf):
         h = self.hidden
@@ -444,18 +470,25 @@ class MVTracker(nn.Module):
         dn = torch.empty(n * S, C, device=dev)
         nsegs = [self._nseg(store["P"][lvl], K) for lvl in range(L)]
         keys = [torch.empty(n * S * nsegs[lvl] * K, device=dev, dtype=torch.int64) for lvl in range(L)]
-        idx_dbg = torch.empty(L, n, S, K, device=dev, dtype=torch.int32) if trace is not None else None
+        # neighbour indices of every level: returned for tracing AND used to seed (prune) the next exact scan
+        idx = torch.empty(L, n, S, K, device=dev, dtype=torch.int32)
+        grid = [tuple(store["xyz"][lvl].shape[2:4]) for lvl in range(L)]  # per-view (h, w) of each level
         preds = []
         for it in range(iters):
-            for lvl in range(L):
+            for lvl in reversed(range(L)):  # coarse to fine: level l+1's neighbours bound level l's first scan
                 P = store["P"][lvl]
-                hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl])
+                seed = {}
+                if it > 0:
+                    seed = dict(seed_idx=idx[lvl], seed_k=K)
+                elif lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
+                    seed = dict(seed_idx=idx[lvl + 1], seed_k=K, seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
+                hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl], **seed)
                 hip.corr_gather_dot(store["xyz"][lvl], store["fvec"][lvl], P, C, ffeats, coords, keys[lvl], n, S, frame0, 1, T, K,
-                                    nsegs[lvl], fcorr, Fc, lvl * K * 4, idx_dbg[lvl] if idx_dbg is not None else None)
+                                    nsegs[lvl], fcorr, Fc, lvl * K * 4, idx[lvl])
             hip.token_assemble(coords, fcorr, Fc, ffeats, C, mask_vis, pos, pk["time_embed"], n, S, E, x, ldx)
             self._update_former(pk, x, ldx, n, delta, ldd)
             if trace is not None:
-                trace.setdefault("knn_idx", []).append(idx_dbg.clone())
+                trace.setdefault("knn_idx", []).append(idx.clone())
                 trace.setdefault("fcorrs", []).append(fcorr.clone())
                 trace.setdefault("tokens", []).append(x[:, :D].reshape(n, S, D).clone())
                 trace.setdefault("delta", []).append(delta[:, :self.out_dim].reshape(n, S, -1).clone())

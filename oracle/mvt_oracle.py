@@ -600,7 +600,7 @@ def tracker_forward(W, cfg: TrackerConfig, rgbs: Tensor, depths: Tensor, query_p
                 if int(m.sum()) == 0:
                     continue
                 _, nn_idx = knn(1, xyz[t - t0][None], qxyz_s[0, p0:p1][m][None], knn_mode)
-                f_init[0, m] = fvec[t - t0][nn_idx[0, :, 0]]
+                f_init[0, m] = fvec[t - t0][nn_idx[0, :, 0]].float()
                 if trace is not None:
                     trace.setdefault("init_idx", []).append((t, nn_idx[0, :, 0].clone()))
             f_init = f_init[:, None].repeat(1, S, 1, 1)

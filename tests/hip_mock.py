@@ -34,12 +34,56 @@ def gemm(A, lda, Wt, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=0):
     _v(Cm, M, N, ldc).copy_(y)
 
 
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def split_bf16(src, hi, lo, n):
+    s = src.reshape(-1)[:n]
+    h = s.to(torch.bfloat16)
+    hi.reshape(-1)[:n].copy_(h.view(torch.int16))
+    if lo is not None:
+        lo.reshape(-1)[:n].copy_((s - h.float()).to(torch.bfloat16).view(torch.int16))
+
+
+def _w_from_bf16(whi, wlo, rows, ld):
+    w = torch.as_strided(whi, (rows, ld), (ld, 1)).view(torch.bfloat16).float()
+    if wlo is not None:
+        w = w + torch.as_strided(wlo, (rows, ld), (ld, 1)).view(torch.bfloat16).float()
+    return w
+
+
+def gemm_bf16(A, lda, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=0):
+    assert ldw % 64 == 0 and ldw >= K
+    a = _v(A, M, K, lda)
+    w = _w_from_bf16(Whi, Wlo, N, ldw)
+    assert float(w[:, K:].abs().sum()) == 0.0
+    if Wlo is None:
+        a = _bf(a)
+    y = a @ w[:, :K].t()
+    if bias is not None:
+        y = y + bias[:N]
+    y = _act(y, act)
+    if R is not None:
+        y = y + _v(R, M, N, ldr)
+    _v(Cm, M, N, ldc).copy_(y)
+
+
+def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0):
+    K = KH * 32 if Cin == 4 else KH * KW * Cin
+    ld = (K + 63) // 64 * 64
+    w = _w_from_bf16(wt_hi, wt_lo, Cout, ld).contiguous()
+    xin = x if wt_lo is not None else _bf(x)
+    conv2d(xin, w, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act)
+
+
 def conv2d(x, wt, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0):
     xi = torch.as_strided(x, (n, H, W, Cin), (H * W * Cin, W * Cin, Cin, 1)).permute(0, 3, 1, 2)
+    ld = ((KH * 32 if Cin == 4 else KH * KW * Cin) + 63) // 64 * 64
     if Cin == 4:
-        w = torch.as_strided(wt, (Cout, KH, 8, 4), (KH * 32, 32, 4, 1))[:, :, :KW, :].permute(0, 3, 1, 2)
+        w = torch.as_strided(wt, (Cout, KH, 8, 4), (ld, 32, 4, 1))[:, :, :KW, :].permute(0, 3, 1, 2)
     else:
-        w = torch.as_strided(wt, (Cout, KH, KW, Cin), (KH * KW * Cin, KW * Cin, Cin, 1)).permute(0, 3, 1, 2)
+        w = torch.as_strided(wt, (Cout, KH, KW, Cin), (ld, KW * Cin, Cin, 1)).permute(0, 3, 1, 2)
     y = _act(F.conv2d(xi, w, bias, stride=stride, padding=pad), act)
     Ho, Wo = y.shape[-2:]
     torch.as_strided(out, (n, Ho, Wo, Cout), (Ho * Wo * ldo, Wo * ldo, ldo, 1)).copy_(y.permute(0, 2, 3, 1))
@@ -130,7 +174,16 @@ def _d2(ref, q):
     return (dz * dz + acc.double()).float()
 
 
-def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys):
+def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_idx=None, seed_k=0, seed_dims=(0, 0, 0, 0)):
+    # the seed only prunes; the result is the exact kNN either way.  Check the seed contract: valid distinct indices.
+    if seed_idx is not None:
+        si = seed_idx.reshape(N, S, seed_k).long()
+        cw, ch, fw, fh = seed_dims
+        if cw > 0:
+            v, rem = si // (cw * ch), si % (cw * ch)
+            si = (v * fh + 2 * (rem // cw)) * fw + 2 * (rem % cw)
+        assert seed_k >= K and int(si.min()) >= 0 and int(si.max()) < Pn
+        assert all(len(set(row.tolist())) == seed_k for row in si.reshape(-1, seed_k)[:64])
     X = torch.as_strided(xyz, (T, Pn, 4), (Pn * 4, 4, 1))
     c = torch.as_strided(coords, (N, S, 3), (S * 3, 3, 1))
     kv = torch.as_strided(keys, (N, S, nseg, K), (S * nseg * K, nseg * K, K, 1))
@@ -240,7 +293,7 @@ def install(monkeypatch):
     import sys
     from mvtracker_amd import hip
     me = sys.modules[__name__]
-    for name in ("gemm conv2d rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
+    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
                  "depth_subsample avgpool2 unproject knn_scan corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

@@ -36,18 +36,30 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def pad_w(w):
+def pad_w(w, mult=64):
     n, k = w.shape
-    wp = torch.zeros(n, (k + 31) // 32 * 32)
+    wp = torch.zeros(n, (k + mult - 1) // mult * mult)
     wp[:, :k] = w
     return wp
+
+
+def split(hip, wp, lo=True):
+    """fp32 [N][Kp] on device -> (bf16 hi, bf16 lo | None) int16 tensors through the library."""
+    hi = torch.empty(wp.shape, device=DEV, dtype=torch.int16)
+    l = torch.empty(wp.shape, device=DEV, dtype=torch.int16) if lo else None
+    hip.split_bf16(wp, hi, l, wp.numel())
+    return hi, l
+
+
+PREC_TOL = {"fp32": 2e-6, "bf16x3": 2e-5, "bf16": 2e-2}
 
 
 # ----------------------------------------------------------------------------------------- GEMM / conv
 @pytest.mark.parametrize("M,N,K,act,res", [(300, 256, 581, 0, False), (1000, 131, 256, 1, False), (768, 288, 256, 0, False),
                                            (517, 1024, 256, 2, False), (400, 256, 1024, 0, True), (130, 128, 128, 3, True),
                                            (64, 64, 32, 0, False), (2000, 864, 256, 0, False), (33, 131, 131, 1, False)])
-def test_gemm(hip, M, N, K, act, res):
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
+def test_gemm(hip, M, N, K, act, res, prec):
     g = torch.Generator().manual_seed(M + N + K)
     lda = (K + 3) // 4 * 4
     A = torch.zeros(M, lda)
@@ -62,9 +74,13 @@ def test_gemm(hip, M, N, K, act, res):
     ldc = N + 5
     C = torch.full((M, ldc), 7.0, device=DEV)
     Wp = G(pad_w(W))
-    hip.gemm(G(A), lda, Wp, Wp.shape[1], G(b), G(R) if res else None, N, C, ldc, M, N, K, act)
+    if prec == "fp32":
+        hip.gemm(G(A), lda, Wp, Wp.shape[1], G(b), G(R) if res else None, N, C, ldc, M, N, K, act)
+    else:
+        hi, lo = split(hip, Wp, prec == "bf16x3")
+        hip.gemm_bf16(G(A), lda, hi, lo, Wp.shape[1], G(b), G(R) if res else None, N, C, ldc, M, N, K, act)
     torch.cuda.synchronize()
-    assert rel_err(C[:, :N], ref) < 2e-6
+    assert rel_err(C[:, :N], ref) < PREC_TOL[prec]
     assert bool((C[:, N:] == 7.0).all())  # nothing written outside the N columns
 
 
@@ -73,8 +89,9 @@ CONVS = [  # n, H, W, Cin, Cout, k, stride, pad
     (1, 16, 24, 416, 256, 3, 1, 1), (3, 9, 11, 256, 128, 1, 1, 0), (1, 20, 20, 128, 128, 3, 2, 1)]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("cfg", CONVS)
-def test_conv2d(hip, cfg):
+def test_conv2d(hip, cfg, prec):
     n, H, W, Cin, Cout, k, s, p = cfg
     g = torch.Generator().manual_seed(sum(cfg))
     x = torch.randn(n, Cin, H, W, generator=g)
@@ -91,9 +108,24 @@ def test_conv2d(hip, cfg):
         xin, wt, cin = x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).contiguous(), Cin
     Ho, Wo = ref.shape[-2:]
     out = torch.empty(n, Ho, Wo, Cout, device=DEV)
-    hip.conv2d(G(xin), G(wt), G(b), out, n, H, W, cin, Cout, k, k, s, p, Cout)
+    wp = G(pad_w(wt.reshape(Cout, -1)))
+    if prec == "fp32":
+        hip.conv2d(G(xin), wp, G(b), out, n, H, W, cin, Cout, k, k, s, p, Cout)
+    else:
+        hi, lo = split(hip, wp, prec == "bf16x3")
+        hip.conv2d_bf16(G(xin), hi, lo, G(b), out, n, H, W, cin, Cout, k, k, s, p, Cout)
     torch.cuda.synchronize()
-    assert rel_err(out.permute(0, 3, 1, 2), ref) < 2e-6
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < PREC_TOL[prec]
+
+
+def test_split_bf16(hip):
+    x = torch.randn(4096) * 3
+    hi = torch.empty(4096, device=DEV, dtype=torch.int16)
+    lo = torch.empty(4096, device=DEV, dtype=torch.int16)
+    hip.split_bf16(G(x), hi, lo, 4096)
+    h = x.to(torch.bfloat16)
+    assert torch.equal(hi.cpu().view(torch.bfloat16), h)
+    assert torch.equal(lo.cpu().view(torch.bfloat16), (x - h.float()).to(torch.bfloat16))
 
 
 def test_conv2d_rejects_bad_args(hip):
@@ -220,6 +252,46 @@ def test_knn_exact_vs_oracle(hip, P, K, nseg, M):
     assert bool((kv[..., 1:] > kv[..., :-1]).all())  # every per-segment list strictly ascending (sortedness)
 
 
+def test_knn_seeded_scan_is_exact(hip):
+    """A seed only prunes: neighbours of moved queries, seeded with the neighbours of the old positions
+    (same level) or with the coarser level's neighbours, equal the unseeded oracle result bit for bit."""
+    g = torch.Generator().manual_seed(11)
+    V, h, w, K, M, B = 2, 32, 48, 16, 40, 3
+    P = V * h * w
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    base = torch.stack([xs * 0.05, ys * 0.05, torch.zeros_like(xs)], -1).reshape(1, 1, h * w, 3)
+    xyz = (base + torch.rand(B, V, h * w, 3, generator=g) * 0.02 + torch.arange(V).view(1, V, 1, 1) * 0.013).reshape(B, P, 3)
+    x4 = torch.zeros(B, P, 4)
+    x4[..., :3] = xyz
+    q0 = torch.rand(M, B, 3, generator=g) * torch.tensor([2.0, 1.4, 0.02])
+    keys = torch.empty(M * B * 2 * K, device=DEV, dtype=torch.int64)
+    out = torch.zeros(M, B, K * 4, device=DEV)
+    idx0 = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
+    fv, tg = torch.randn(B, P, 128, generator=g), torch.randn(M, B, 128, generator=g)
+    hip.knn_scan(G(x4), P, G(q0), M, B, 0, 1, B, K, 2, keys)
+    hip.corr_gather_dot(G(x4), G(fv), P, 128, G(tg), G(q0), keys, M, B, 0, 1, B, K, 2, out, K * 4, 0, idx0)
+    q1 = q0 + torch.randn(M, B, 3, generator=g) * 0.01
+    idx1 = torch.empty_like(idx0)
+    hip.knn_scan(G(x4), P, G(q1), M, B, 0, 1, B, K, 2, keys, seed_idx=idx0, seed_k=K)
+    hip.corr_gather_dot(G(x4), G(fv), P, 128, G(tg), G(q1), keys, M, B, 0, 1, B, K, 2, out, K * 4, 0, idx1)
+    _, ref = O.knn_exact(K, xyz, q1.permute(1, 0, 2))
+    assert torch.equal(idx1.cpu().long().permute(1, 0, 2), ref)
+    # coarse level = every second pixel of the same grid; its neighbours seed the fine scan
+    hc, wc = h // 2, w // 2
+    xc = xyz.reshape(B, V, h, w, 3)[:, :, ::2, ::2].reshape(B, V * hc * wc, 3)
+    x4c = torch.zeros(B, V * hc * wc, 4)
+    x4c[..., :3] = xc
+    kc = torch.empty(M * B * K, device=DEV, dtype=torch.int64)
+    idxc = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
+    hip.knn_scan(G(x4c), V * hc * wc, G(q1), M, B, 0, 1, B, K, 1, kc)
+    hip.corr_gather_dot(G(x4c), G(fv[:, :V * hc * wc]), V * hc * wc, 128, G(tg), G(q1), kc, M, B, 0, 1, B, K, 1, out, K * 4, 0, idxc)
+    idx2 = torch.empty_like(idx0)
+    hip.knn_scan(G(x4), P, G(q1), M, B, 0, 1, B, K, 2, keys, seed_idx=idxc, seed_k=K, seed_dims=(wc, hc, w, h))
+    hip.corr_gather_dot(G(x4), G(fv), P, 128, G(tg), G(q1), keys, M, B, 0, 1, B, K, 2, out, K * 4, 0, idx2)
+    torch.cuda.synchronize()
+    assert torch.equal(idx2.cpu().long().permute(1, 0, 2), ref)
+
+
 def test_knn_duplicate_points_tie_break(hip):
     # exact ties: the lower index must win (ordering by (d2, index))
     P, K = 300, 16
@@ -299,10 +371,11 @@ def test_layernorm(hip):
     assert (y.cpu() - F.layer_norm(x, (256,), w, b, 1e-5)).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("n", [50, 200, 1024])
 @pytest.mark.parametrize("mode", ["time", "v2p", "vself", "p2v"])
-def test_attention(hip, mode):
+def test_attention(hip, mode, n):
     g = torch.Generator().manual_seed(3)
-    n, nv, S, H, dh = 50, 64, 12, 6, 48
+    nv, S, H, dh = 64, 12, 6, 48
     inner = H * dh
     M = (n + nv) * S
     qkv = torch.randn(M, 3 * inner, generator=g)
