@@ -7,7 +7,8 @@
 
 One "step" = one full tracker call (encode 4 views x 24 frames of 512x512, build the frame store,
 3 sliding windows x 4 refinement iterations, 1024 queries) on synthetic inputs already resident in HBM
-(BASELINE.json config "4-view 24-frame 512x512 @1024 queries").  With N > 1 every rank tracks its own
+(BASELINE.json config "4-view 24-frame 512x512 @1024 queries"; one corr_gather_dot launch covers the 4 pyramid
+levels of one refinement iteration = 4 x 12288 units x 9164 B = 450 MB of algorithmic traffic).  With N > 1 every rank tracks its own
 1024-query shard (weak scaling; shard = independent forward) and the frames are
 encoded once across the node: rank r encodes frames r, r+N, ... and the level-0 feature maps are
 all-gathered over RCCL/xGMI before the refinement loop, which contains no collective.
@@ -152,7 +153,7 @@ def main():
         value = world * Nq * T / (dt / args.steps)
         full = [(e0.elapsed_time(e1), rows) for e0, e1, rows in events if rows == Nq * model.S]
         kern_ms = float(np.mean([m for m, _ in full])) if full else float("nan")
-        alg = corr_algorithmic_bytes(Nq * model.S, model.corr_neighbors, model.latent_dim)
+        alg = model.corr_n_levels * corr_algorithmic_bytes(Nq * model.S, model.corr_neighbors, model.latent_dim)
         achieved = alg / (kern_ms * 1e-3) / 1e9 if full else float("nan")
         out = {
             "metric": "query-points*frames/sec, 4-view 24-frame 512x512 @1024 queries",

@@ -149,15 +149,18 @@ int mvt_unproject(const float* depth_s, const float* kinv, const float* einv, fl
 int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step,
                  int T, int K, int nseg, unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw,
                  int seed_ch, int seed_fw, int seed_fh, void* stream);
-/* Gather-dot for one pyramid level: merges the nseg partial lists of mvt_knn_scan, gathers the
- * K neighbour rows of fvec [T][P][C] (C % 4 == 0, C <= 256, groups == 1) and writes, for
- * k < K:  out[(n*S+s)*ldo + o_off + 4k + {0,1,2,3}] = { <target, f_k>/sqrt(C), xyz_k - coord }
- * (mvtracker.py:827-842 with corr_add_neighbor_offset=True).  targets [N][S][C].  idx_out
- * (optional) [N][S][K] int32 receives the neighbour indices. */
-int mvt_corr_gather_dot(const float* xyz, const float* fvec, long long P, int C, const float* targets,
-                        const float* coords, const unsigned long long* keys, int N, int S, int frame0,
-                        int frame_step, int T, int K, int nseg, float* out, int ldo, int o_off, int* idx_out,
-                        void* stream);
+/* Merge the nseg per-segment key lists of mvt_knn_scan: idx_out [N][S][K] int32 = the K nearest neighbour
+ * indices, ascending by (d2, index); indices are clamped to [0, P) (only NaN queries can be out of range). */
+int mvt_knn_merge(const unsigned long long* keys, int N, int S, int K, int nseg, long long P, int* idx_out,
+                  void* stream);
+/* Gather-dot correlation for `levels` pyramid levels in ONE launch (grid.y = level).  Host arrays of per-level
+ * DEVICE pointers: xyz[l] [T][P_l][4], fvec[l] [T][P_l][C] (C in {32,64,128,256}, groups == 1), idx[l]
+ * [N][S][K] int32 from mvt_knn_merge, P[l].  For k < K:
+ *   out[(n*S+s)*ldo + o_off + l*4K + 4k + {0,1,2,3}] = { <target, f_k>/sqrt(C), xyz_k - coord }
+ * (mvtracker.py:827-842 with corr_add_neighbor_offset=True; the level-major concat of :374).  targets [N][S][C]. */
+int mvt_corr_gather_dot(int levels, const float* const* xyz, const float* const* fvec, const long long* P,
+                        const int* const* idx, int C, const float* targets, const float* coords, int N, int S,
+                        int frame0, int frame_step, int T, int K, float* out, int ldo, int o_off, void* stream);
 /* 1-NN feature init: feat_out[n][C] = fvec[frame][idx] with idx from keys [n][1][nseg][1]
  * (mvtracker.py:640-643); idx_out optional. */
 int mvt_knn1_gather(const float* fvec, long long P, int C, const unsigned long long* keys, int n, int nseg,

@@ -150,16 +150,25 @@ __global__ __launch_bounds__(256) void attention_klane_kernel(const float* __res
 }
 
 // Queries on lanes, keys wave-uniform: a wave owns 64 consecutive queries of one (group, head); every key / value
-// row is the same for all lanes, so it is fetched with scalar loads and feeds the FMAs from SGPRs (no LDS, no
-// per-lane K/V traffic).  KS > 1 splits the keys of one query chunk over KS waves whose online-softmax states are
-// merged through LDS (virtual<-point attention: 64 queries x 1024 keys).
+// row is the same for all lanes.  The wave stages CH keys at a time into its private LDS slice (coalesced 16-B
+// loads, the next chunk already in flight in registers while the current one is consumed) and reads them back as
+// broadcast ds_read_b128, so the FMAs never wait on global latency.  KS > 1 splits the keys of one query chunk over
+// KS waves whose online-softmax states are merged through LDS (virtual<-point attention: 64 queries x 1024 keys).
 template <int DH, int KS>
 __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_ukeys_kernel(
     const float* __restrict__ q, int ldq, long long q_gs, long long q_is, const float* __restrict__ k, const float* __restrict__ v,
     int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads) {
-  __shared__ float red[(KS > 1 ? (KS - 1) * 64 * (DH + 2) : 1)];
+  constexpr int NW = KS == 1 ? 4 : KS;         // waves per block
+  constexpr int CH = 16;                       // keys per staged chunk
+  constexpr int Q4 = DH / 4;                   // float4 per row
+  constexpr int NLD = CH * Q4 / 64;            // float4 per lane per chunk (K and V each)
+  constexpr int STAGE = NW * 2 * CH * DH;      // floats
+  constexpr int MERGE = KS > 1 ? (KS - 1) * 64 * (DH + 2) : 0;
+  __shared__ __attribute__((aligned(16))) float lds[STAGE > MERGE ? STAGE : MERGE];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sk = lds + wave * 2 * CH * DH;
+  float* sv = sk + CH * DH;
   const int chunks = (nq + 63) / 64;
   const long long nchunk = (long long)groups * heads * chunks;
   const long long chunk_id = KS == 1 ? (long long)blockIdx.x * 4 + wave : (long long)blockIdx.x;
@@ -187,36 +196,72 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_ukeys_kerne
   const int per = (nk + KS - 1) / KS;
   const int j0 = KS == 1 ? 0 : wave * per;
   const int j1 = KS == 1 ? nk : (j0 + per < nk ? j0 + per : nk);
-  const float* kp = k + (g * k_gs + (long long)j0 * k_is) * ldkv + hd * DH;
-  const float* vp = v + (g * k_gs + (long long)j0 * k_is) * ldkv + hd * DH;
   const long long kstep = k_is * ldkv;
+  const float* kb = k + (g * k_gs) * ldkv + hd * DH;
+  const float* vb = v + (g * k_gs) * ldkv + hd * DH;
+
+  f32x4 rk[NLD], rv[NLD];
+  auto fetch = [&](int jc) {  // keys jc .. jc+CH-1 of this wave's range -> registers
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = i * 64 + lane;
+      const int key = f / Q4, c4 = f - key * Q4;
+      rk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (jc + key < j1) {
+        rk[i] = *reinterpret_cast<const f32x4*>(kb + (long long)(jc + key) * kstep + c4 * 4);
+        rv[i] = *reinterpret_cast<const f32x4*>(vb + (long long)(jc + key) * kstep + c4 * 4);
+      }
+    }
+  };
+  if (j0 < j1) fetch(j0);
 #pragma unroll 1
-  for (int j = j0; j < j1; ++j, kp += kstep, vp += kstep) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int jc = j0; jc < j1; jc += CH) {
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int d = 0; d < DH; d += 4) {
-      s0 = fmaf(qv[d], kp[d], s0);
-      s1 = fmaf(qv[d + 1], kp[d + 1], s1);
-      s2 = fmaf(qv[d + 2], kp[d + 2], s2);
-      s3 = fmaf(qv[d + 3], kp[d + 3], s3);
+    for (int i = 0; i < NLD; ++i) {
+      *reinterpret_cast<f32x4*>(sk + (i * 64 + lane) * 4) = rk[i];
+      *reinterpret_cast<f32x4*>(sv + (i * 64 + lane) * 4) = rv[i];
     }
-    const float s = (s0 + s1) + (s2 + s3);
-    if (__ballot(s > m)) {  // some lane has a new running maximum: rescale (rare after the first keys)
-      const float mn = fmaxf(m, s);
-      const float corr = expf(m - mn);
-      l *= corr;
+    __builtin_amdgcn_wave_barrier();
+    if (jc + CH < j1) fetch(jc + CH);  // next chunk in flight while this one is consumed
+    const int nkeys = j1 - jc < CH ? j1 - jc : CH;
+#pragma unroll 1
+    for (int kk = 0; kk < nkeys; ++kk) {
+      const f32x4* kr = reinterpret_cast<const f32x4*>(sk + kk * DH);
+      const f32x4* vr = reinterpret_cast<const f32x4*>(sv + kk * DH);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) acc[d] *= corr;
-      m = mn;
+      for (int d = 0; d < Q4; ++d) {
+        const f32x4 t = kr[d];
+        s0 = fmaf(qv[4 * d], t[0], s0);
+        s1 = fmaf(qv[4 * d + 1], t[1], s1);
+        s2 = fmaf(qv[4 * d + 2], t[2], s2);
+        s3 = fmaf(qv[4 * d + 3], t[3], s3);
+      }
+      const float sc = (s0 + s1) + (s2 + s3);
+      if (__ballot(sc > m)) {  // some lane has a new running maximum: rescale (rare after the first keys)
+        const float mn = fmaxf(m, sc);
+        const float corr = expf(m - mn);
+        l *= corr;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] *= corr;
+        m = mn;
+      }
+      const float p = expf(sc - m);
+      l += p;
+#pragma unroll
+      for (int d = 0; d < Q4; ++d) {
+        const f32x4 t = vr[d];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * d + e] = fmaf(p, t[e], acc[4 * d + e]);
+      }
     }
-    const float p = expf(s - m);
-    l += p;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) acc[d] = fmaf(p, vp[d], acc[d]);
   }
   if (KS > 1) {
+    __syncthreads();  // every wave is done with its staging slice: the merge image may overlay it
     if (wave > 0) {
-      float* r = red + ((wave - 1) * 64 + lane) * (DH + 2);
+      float* r = lds + ((wave - 1) * 64 + lane) * (DH + 2);
       r[0] = m;
       r[1] = l;
 #pragma unroll
@@ -226,7 +271,7 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_ukeys_kerne
     if (wave > 0) return;
 #pragma unroll 1
     for (int w = 0; w < KS - 1; ++w) {
-      const float* r = red + (w * 64 + lane) * (DH + 2);
+      const float* r = lds + (w * 64 + lane) * (DH + 2);
       const float mw = r[0];
       const float mn = fmaxf(m, mw);
       const float ca = (m == -INFINITY) ? 0.f : expf(m - mn);

@@ -225,38 +225,59 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   }
 }
 
-// lanes [0, E) hold keys; returns in lane r (r < K) the r-th smallest.  E <= 64.
-__device__ __forceinline__ unsigned long long merge_keys(unsigned long long e, int K, int lane) {
-  unsigned long long mine = KEY_MAX;
-  for (int r = 0; r < K; ++r) {
-    unsigned long long m = wave_min_u64(e);
-    if (e == m) e = KEY_MAX;
-    if (lane == r) mine = m;
+// Merge the nseg per-segment lists of one (track, slot) into its K nearest neighbour indices.  Every lane holds
+// one key; its rank among the E = nseg*K keys is counted with wave-uniform readlane broadcasts (keys are unique).
+__global__ __launch_bounds__(256) void knn_merge_kernel(const unsigned long long* __restrict__ keys, long long rows, int K, int nseg,
+                                                        long long P, int* __restrict__ idx_out) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int E = nseg * K;
+  const unsigned long long key = lane < E ? keys[row * E + lane] : KEY_MAX;
+  int rank = lane;
+  if (nseg > 1) {
+    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+    rank = 0;
+#pragma unroll 1
+    for (int j = 0; j < E; ++j) {
+      const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+      rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;  // KEY_MAX padding ties are broken by lane
+    }
   }
-  return mine;
+  if (lane < E && rank < K) {
+    unsigned idx = (unsigned)key;
+    if ((long long)idx >= P) idx = (unsigned)(P - 1);  // only reachable with NaN coordinates; stay in bounds
+    idx_out[row * K + rank] = (int)idx;
+  }
 }
 
+struct CorrLevels {
+  const float* xyz[8];
+  const float* fvec[8];
+  const int* idx[8];
+  long long P[8];
+};
+
 template <int LPR>  // lanes per feature row: C = 4 * LPR
-__global__ __launch_bounds__(256) void corr_gather_dot_kernel(const float* __restrict__ xyz, const float* __restrict__ fvec, long long P,
-                                                              const float* __restrict__ targets, const float* __restrict__ coords,
-                                                              const unsigned long long* __restrict__ keys, int N, int S, int frame0,
-                                                              int frame_step, int T, int K, int nseg, float* __restrict__ out, int ldo,
-                                                              int o_off, int* __restrict__ idx_out) {
+__global__ __launch_bounds__(256) void corr_gather_dot_kernel(CorrLevels lv, const float* __restrict__ targets,
+                                                              const float* __restrict__ coords, int N, int S, int frame0,
+                                                              int frame_step, int T, int K, float* __restrict__ out, int ldo, int o_off) {
   constexpr int C = 4 * LPR;
   constexpr int RPL = 64 / LPR;  // rows per wave load
   const int lane = threadIdx.x & 63;
+  const int level = blockIdx.y;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // n * S + s
   if (row >= (long long)N * S) return;
   const int s = (int)(row % S);
   int frame = frame0 + s * frame_step;
   frame = frame < T - 1 ? frame : T - 1;
+  const long long P = lv.P[level];
+  const float* __restrict__ xyz = lv.xyz[level];
+  const float* __restrict__ fvec = lv.fvec[level];
 
-  const int E = nseg * K;
-  unsigned long long key = lane < E ? keys[row * E + lane] : KEY_MAX;
-  if (nseg > 1) key = merge_keys(key, K, lane);
-  unsigned idx = (unsigned)key;
-  if ((long long)idx >= P) idx = (unsigned)(P - 1);  // only reachable with NaN coordinates; stay in bounds
-  if (idx_out && lane < K) idx_out[row * K + lane] = (int)idx;
+  unsigned idx = (unsigned)lv.idx[level][row * K + (lane < K ? lane : 0)];
+  if ((long long)idx >= P) idx = (unsigned)(P - 1);
 
   const int sub = lane / LPR, cq = lane % LPR;
   const f32x4 tg = *reinterpret_cast<const f32x4*>(targets + row * C + cq * 4);
@@ -289,7 +310,7 @@ __global__ __launch_bounds__(256) void corr_gather_dot_kernel(const float* __res
     if (lane / RPL == j) mine = v;
   }
   if (lane < K) {
-    float* o = out + row * ldo + o_off + lane * 4;
+    float* o = out + row * ldo + o_off + level * K * 4 + lane * 4;
     o[0] = mine / scale;
     o[1] = ox;
     o[2] = oy;
@@ -384,16 +405,32 @@ extern "C" int mvt_knn_scan(const float* xyz, long long P, const float* coords, 
   return mvt_launch_status();
 }
 
-extern "C" int mvt_corr_gather_dot(const float* xyz, const float* fvec, long long P, int C, const float* targets,
-                                   const float* coords, const unsigned long long* keys, int N, int S, int frame0, int frame_step,
-                                   int T, int K, int nseg, float* out, int ldo, int o_off, int* idx_out, void* stream) {
-  MVT_REQUIRE(xyz && fvec && targets && coords && keys && out && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T);
-  MVT_REQUIRE(K >= 1 && K <= 16 && nseg >= 1 && nseg * K <= 64 && P >= K && P < (1LL << 31) && frame_step >= 0);
-  MVT_REQUIRE(o_off >= 0 && ldo >= o_off + 4 * K);
-  const unsigned blocks = (unsigned)mvt_cdiv((long long)N * S, 4);
-#define LAUNCH(LPR)                                                                                                             \
-  hipLaunchKernelGGL((corr_gather_dot_kernel<LPR>), dim3(blocks), dim3(256), 0, mvt_stream(stream), xyz, fvec, P, targets, coords, \
-                     keys, N, S, frame0, frame_step, T, K, nseg, out, ldo, o_off, idx_out)
+extern "C" int mvt_knn_merge(const unsigned long long* keys, int N, int S, int K, int nseg, long long P, int* idx_out, void* stream) {
+  MVT_REQUIRE(keys && idx_out && N > 0 && S > 0 && K >= 1 && K <= 16 && nseg >= 1 && nseg * K <= 64 && P >= K);
+  const long long rows = (long long)N * S;
+  hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)mvt_cdiv(rows, 4)), dim3(256), 0, mvt_stream(stream), keys, rows, K, nseg, P,
+                     idx_out);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_corr_gather_dot(int levels, const float* const* xyz, const float* const* fvec, const long long* P,
+                                   const int* const* idx, int C, const float* targets, const float* coords, int N, int S,
+                                   int frame0, int frame_step, int T, int K, float* out, int ldo, int o_off, void* stream) {
+  MVT_REQUIRE(levels >= 1 && levels <= 8 && xyz && fvec && P && idx && targets && coords && out);
+  MVT_REQUIRE(N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0 && K >= 1 && K <= 16);
+  MVT_REQUIRE(o_off >= 0 && ldo >= o_off + levels * 4 * K);
+  CorrLevels lv{};
+  for (int l = 0; l < levels; ++l) {
+    MVT_REQUIRE(xyz[l] && fvec[l] && idx[l] && P[l] >= K && P[l] < (1LL << 31));
+    lv.xyz[l] = xyz[l];
+    lv.fvec[l] = fvec[l];
+    lv.idx[l] = idx[l];
+    lv.P[l] = P[l];
+  }
+  const dim3 grid((unsigned)mvt_cdiv((long long)N * S, 4), (unsigned)levels);
+#define LAUNCH(LPR)                                                                                                              \
+  hipLaunchKernelGGL((corr_gather_dot_kernel<LPR>), grid, dim3(256), 0, mvt_stream(stream), lv, targets, coords, N, S, frame0, frame_step, \
+                     T, K, out, ldo, o_off)
   switch (C) {
     case 32: LAUNCH(8); break;
     case 64: LAUNCH(16); break;

@@ -42,7 +42,8 @@ SIGNATURES = {
     "mvt_avgpool2": [P, P, LL, I, I, I, P],
     "mvt_unproject": [P, P, P, P, I, I, I, I, I, I, P],
     "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P],
-    "mvt_corr_gather_dot": [P, P, LL, I, P, P, P, I, I, I, I, I, I, I, P, I, I, P, P],
+    "mvt_knn_merge": [P, I, I, I, I, LL, P, P],
+    "mvt_corr_gather_dot": [I, P, P, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
     "mvt_knn1_gather": [P, LL, I, P, I, I, I, P, P, P],
     "mvt_window_corr": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mvt_pos_embed": [P, I, I, I, I, P, P],
@@ -170,10 +171,17 @@ def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_i
           *seed_dims, _stream())
 
 
-def corr_gather_dot(xyz, fvec, Pn, Cc, targets, coords, keys, N, S, frame0, frame_step, T, K, nseg, out, ldo, o_off,
-                    idx_out=None):
-    _call("mvt_corr_gather_dot", _ptr(xyz), _ptr(fvec), Pn, Cc, _ptr(targets), _ptr(coords), _ptr(keys), N, S, frame0,
-          frame_step, T, K, nseg, _ptr(out), ldo, o_off, _ptr(idx_out), _stream())
+def knn_merge(keys, N, S, K, nseg, Pn, idx_out):
+    _call("mvt_knn_merge", _ptr(keys), N, S, K, nseg, Pn, _ptr(idx_out), _stream())
+
+
+def corr_gather_dot(xyz_l, fvec_l, P_l, idx_l, Cc, targets, coords, N, S, frame0, frame_step, T, K, out, ldo, o_off):
+    """xyz_l / fvec_l / idx_l: lists of per-level device tensors; P_l: list of point counts."""
+    n = len(xyz_l)
+    pa = (C.c_void_p * n)
+    _call("mvt_corr_gather_dot", n, pa(*[_ptr(t) for t in xyz_l]), pa(*[_ptr(t) for t in fvec_l]), (C.c_longlong * n)(*P_l),
+          pa(*[_ptr(t) for t in idx_l]), Cc, _ptr(targets), _ptr(coords), N, S, frame0, frame_step, T, K, _ptr(out), ldo, o_off,
+          _stream())
 
 
 def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):

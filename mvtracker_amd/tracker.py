@@ -483,8 +483,9 @@ class MVTracker(nn.Module):
                 elif lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
                     seed = dict(seed_idx=idx[lvl + 1], seed_k=K, seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
                 hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl], **seed)
-                hip.corr_gather_dot(store["xyz"][lvl], store["fvec"][lvl], P, C, ffeats, coords, keys[lvl], n, S, frame0, 1, T, K,
-                                    nsegs[lvl], fcorr, Fc, lvl * K * 4, idx[lvl])
+                hip.knn_merge(keys[lvl], n, S, K, nsegs[lvl], P, idx[lvl])
+            hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0, 1,
+                                T, K, fcorr, Fc, 0)
             hip.token_assemble(coords, fcorr, Fc, ffeats, C, mask_vis, pos, pk["time_embed"], n, S, E, x, ldx)
             self._update_former(pk, x, ldx, n, delta, ldd)
             if trace is not None:

@@ -197,22 +197,25 @@ def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_i
             kv[:, s, g] = torch.topk(seg, K, dim=1, largest=False, sorted=True).values
 
 
-def corr_gather_dot(xyz, fvec, Pn, Cc, targets, coords, keys, N, S, frame0, frame_step, T, K, nseg, out, ldo, o_off,
-                    idx_out=None):
-    X = torch.as_strided(xyz, (T, Pn, 4), (Pn * 4, 4, 1))
-    Fv = torch.as_strided(fvec, (T, Pn, Cc), (Pn * Cc, Cc, 1))
+def knn_merge(keys, N, S, K, nseg, Pn, idx_out):
     kv = torch.as_strided(keys, (N, S, nseg * K), (S * nseg * K, nseg * K, 1))
-    idx = torch.sort(kv, dim=2).values[:, :, :K] & 0xFFFFFFFF
+    idx = (torch.sort(kv, dim=2).values[:, :, :K] & 0xFFFFFFFF).clamp(max=Pn - 1)
+    idx_out.reshape(N, S, K).copy_(idx.int())
+
+
+def corr_gather_dot(xyz_l, fvec_l, P_l, idx_l, Cc, targets, coords, N, S, frame0, frame_step, T, K, out, ldo, o_off):
     tg = torch.as_strided(targets, (N, S, Cc), (S * Cc, Cc, 1))
     c = torch.as_strided(coords, (N, S, 3), (S * 3, 3, 1))
-    o = torch.as_strided(out, (N, S, K, 4), (S * ldo, ldo, 4, 1), out.storage_offset() + o_off)
-    for s in range(S):
-        f = min(frame0 + s * frame_step, T - 1)
-        nf = Fv[f][idx[:, s]]
-        o[:, s, :, 0] = torch.einsum("nc,nkc->nk", tg[:, s], nf) / math.sqrt(Cc)
-        o[:, s, :, 1:] = X[f][idx[:, s]][..., :3] - c[:, s, None]
-    if idx_out is not None:
-        idx_out.reshape(N, S, K).copy_(idx.int())
+    for lvl, (xyz, fvec, Pn, idx_t) in enumerate(zip(xyz_l, fvec_l, P_l, idx_l)):
+        X = torch.as_strided(xyz, (T, Pn, 4), (Pn * 4, 4, 1))
+        Fv = torch.as_strided(fvec, (T, Pn, Cc), (Pn * Cc, Cc, 1))
+        idx = idx_t.reshape(N, S, K).long()
+        o = torch.as_strided(out, (N, S, K, 4), (S * ldo, ldo, 4, 1), out.storage_offset() + o_off + lvl * 4 * K)
+        for s in range(S):
+            f = min(frame0 + s * frame_step, T - 1)
+            nf = Fv[f][idx[:, s]]
+            o[:, s, :, 0] = torch.einsum("nc,nkc->nk", tg[:, s], nf) / math.sqrt(Cc)
+            o[:, s, :, 1:] = X[f][idx[:, s]][..., :3] - c[:, s, None]
 
 
 def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):
@@ -294,6 +297,6 @@ def install(monkeypatch):
     from mvtracker_amd import hip
     me = sys.modules[__name__]
     for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
-                 "depth_subsample avgpool2 unproject knn_scan corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
+                 "depth_subsample avgpool2 unproject knn_scan knn_merge corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

@@ -211,7 +211,7 @@ def test_frame_store_kernels(hip, golden):
 
 
 # ----------------------------------------------------------------------------------------- kNN + correlation
-def _run_corr(hip, xyz, fvec, targets, coords, K, nseg):
+def _run_corr(hip, xyz, fvec, targets, coords, K, nseg, seed=None):
     B, P, C = fvec.shape
     M = targets.shape[1]
     x4 = torch.zeros(B, P, 4)
@@ -219,11 +219,13 @@ def _run_corr(hip, xyz, fvec, targets, coords, K, nseg):
     # library layout: tracks major -> use N = M, S = B (slot s reads frame s)
     tg = G(targets.permute(1, 0, 2))
     cd = G(coords.permute(1, 0, 2))
+    x4g, fg = G(x4), G(fvec)
     keys = torch.empty(M * B * nseg * K, device=DEV, dtype=torch.int64)
-    hip.knn_scan(G(x4), P, cd, M, B, 0, 1, B, K, nseg, keys)
-    out = torch.zeros(M, B, K * 4, device=DEV)
+    hip.knn_scan(x4g, P, cd, M, B, 0, 1, B, K, nseg, keys, **(seed or {}))
     idx = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
-    hip.corr_gather_dot(G(x4), G(fvec), P, C, tg, cd, keys, M, B, 0, 1, B, K, nseg, out, K * 4, 0, idx)
+    hip.knn_merge(keys, M, B, K, nseg, P, idx)
+    out = torch.zeros(M, B, K * 4, device=DEV)
+    hip.corr_gather_dot([x4g], [fg], [P], [idx], C, tg, cd, M, B, 0, 1, B, K, out, K * 4, 0)
     torch.cuda.synchronize()
     return out.reshape(M, B, K, 4).permute(1, 0, 2, 3).cpu(), idx.permute(1, 0, 2).cpu().long(), keys
 
@@ -261,35 +263,52 @@ def test_knn_seeded_scan_is_exact(hip):
     ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
     base = torch.stack([xs * 0.05, ys * 0.05, torch.zeros_like(xs)], -1).reshape(1, 1, h * w, 3)
     xyz = (base + torch.rand(B, V, h * w, 3, generator=g) * 0.02 + torch.arange(V).view(1, V, 1, 1) * 0.013).reshape(B, P, 3)
-    x4 = torch.zeros(B, P, 4)
-    x4[..., :3] = xyz
-    q0 = torch.rand(M, B, 3, generator=g) * torch.tensor([2.0, 1.4, 0.02])
-    keys = torch.empty(M * B * 2 * K, device=DEV, dtype=torch.int64)
-    out = torch.zeros(M, B, K * 4, device=DEV)
-    idx0 = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
-    fv, tg = torch.randn(B, P, 128, generator=g), torch.randn(M, B, 128, generator=g)
-    hip.knn_scan(G(x4), P, G(q0), M, B, 0, 1, B, K, 2, keys)
-    hip.corr_gather_dot(G(x4), G(fv), P, 128, G(tg), G(q0), keys, M, B, 0, 1, B, K, 2, out, K * 4, 0, idx0)
-    q1 = q0 + torch.randn(M, B, 3, generator=g) * 0.01
-    idx1 = torch.empty_like(idx0)
-    hip.knn_scan(G(x4), P, G(q1), M, B, 0, 1, B, K, 2, keys, seed_idx=idx0, seed_k=K)
-    hip.corr_gather_dot(G(x4), G(fv), P, 128, G(tg), G(q1), keys, M, B, 0, 1, B, K, 2, out, K * 4, 0, idx1)
-    _, ref = O.knn_exact(K, xyz, q1.permute(1, 0, 2))
-    assert torch.equal(idx1.cpu().long().permute(1, 0, 2), ref)
+    q0 = torch.rand(B, M, 3, generator=g) * torch.tensor([2.0, 1.4, 0.02])
+    fv, tg = torch.randn(B, P, 128, generator=g), torch.randn(B, M, 128, generator=g)
+    _, idx0, _ = _run_corr(hip, xyz, fv, tg, q0, K, 2)
+    q1 = q0 + torch.randn(B, M, 3, generator=g) * 0.01
+    seed0 = G(idx0.permute(1, 0, 2).int())
+    out1, idx1, _ = _run_corr(hip, xyz, fv, tg, q1, K, 2, seed=dict(seed_idx=seed0, seed_k=K))
+    ref_out, ref = O.corr_sample(xyz, fv, tg, q1, K, 1, True, False, "exact", return_idx=True)
+    assert torch.equal(idx1, ref) and (out1 - ref_out).abs().max() < 2e-5
     # coarse level = every second pixel of the same grid; its neighbours seed the fine scan
     hc, wc = h // 2, w // 2
     xc = xyz.reshape(B, V, h, w, 3)[:, :, ::2, ::2].reshape(B, V * hc * wc, 3)
-    x4c = torch.zeros(B, V * hc * wc, 4)
-    x4c[..., :3] = xc
-    kc = torch.empty(M * B * K, device=DEV, dtype=torch.int64)
-    idxc = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
-    hip.knn_scan(G(x4c), V * hc * wc, G(q1), M, B, 0, 1, B, K, 1, kc)
-    hip.corr_gather_dot(G(x4c), G(fv[:, :V * hc * wc]), V * hc * wc, 128, G(tg), G(q1), kc, M, B, 0, 1, B, K, 1, out, K * 4, 0, idxc)
-    idx2 = torch.empty_like(idx0)
-    hip.knn_scan(G(x4), P, G(q1), M, B, 0, 1, B, K, 2, keys, seed_idx=idxc, seed_k=K, seed_dims=(wc, hc, w, h))
-    hip.corr_gather_dot(G(x4), G(fv), P, 128, G(tg), G(q1), keys, M, B, 0, 1, B, K, 2, out, K * 4, 0, idx2)
+    _, idxc, _ = _run_corr(hip, xc, fv[:, :V * hc * wc], tg, q1, K, 1)
+    seedc = G(idxc.permute(1, 0, 2).int())
+    _, idx2, _ = _run_corr(hip, xyz, fv, tg, q1, K, 2, seed=dict(seed_idx=seedc, seed_k=K, seed_dims=(wc, hc, w, h)))
+    assert torch.equal(idx2, ref)
+
+
+def test_corr_all_levels_one_launch(hip):
+    g = torch.Generator().manual_seed(12)
+    B, M, K, C = 2, 30, 16, 128
+    Ps = [2000, 500, 130]
+    xs = [torch.rand(B, P, 3, generator=g) for P in Ps]
+    fs = [torch.randn(B, P, C, generator=g) for P in Ps]
+    tg, cd = torch.randn(B, M, C, generator=g), torch.rand(B, M, 3, generator=g)
+    x4 = []
+    for x in xs:
+        t = torch.zeros(B, x.shape[1], 4)
+        t[..., :3] = x
+        x4.append(G(t))
+    fg = [G(f) for f in fs]
+    tgg, cdg = G(tg.permute(1, 0, 2)), G(cd.permute(1, 0, 2))
+    idx = []
+    for x, P in zip(x4, Ps):
+        keys = torch.empty(M * B * K, device=DEV, dtype=torch.int64)
+        hip.knn_scan(x, P, cdg, M, B, 0, 1, B, K, 1, keys)
+        i = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
+        hip.knn_merge(keys, M, B, K, 1, P, i)
+        idx.append(i)
+    out = torch.zeros(M, B, 5 + 3 * K * 4, device=DEV)
+    hip.corr_gather_dot(x4, fg, Ps, idx, C, tgg, cdg, M, B, 0, 1, B, K, out, 5 + 3 * K * 4, 5)
     torch.cuda.synchronize()
-    assert torch.equal(idx2.cpu().long().permute(1, 0, 2), ref)
+    assert float(out[..., :5].abs().max()) == 0.0
+    for l in range(3):
+        ref = O.corr_sample(xs[l], fs[l], tg, cd, K, 1, True, False, "exact")
+        got = out[..., 5 + l * K * 4:5 + (l + 1) * K * 4].reshape(M, B, K, 4).permute(1, 0, 2, 3).cpu()
+        assert (got - ref).abs().max() < 2e-5
 
 
 def test_knn_duplicate_points_tie_break(hip):
