@@ -73,8 +73,8 @@ def main():
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU")
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default=None,
-                    help="matrix-core arithmetic of convs/linears (default: the model's default)")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="bf16",
+                    help="matrix-core arithmetic of convs/linears; BASELINE.json quotes this config in bf16")
     ap.add_argument("--cpu-hw", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
