@@ -406,6 +406,205 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with an LDS-resident input patch ("halo tile").
+// The im2col loader above re-reads every input pixel 9 times (once per filter tap); at fp32 activations that
+// makes the big encoder convs L2/HBM-bandwidth bound.  Here a workgroup owns an 8x16 block of output pixels:
+// per 32-channel chunk it stages the 10x18 input patch ONCE (converted to bf16 on the way) and the nine taps
+// read it back at shifted offsets, so global traffic per MAC drops ~6x and the kernel becomes MFMA-bound.
+// Weights ([Cout][kh][kw][Cin] bf16, row stride ldw) are staged one filter row (3 taps) at a time.
+// Patch / weight rows are 32+8 bf16 (80 B): conflict-free ds_read_b128, 16-B aligned.
+constexpr int HT = 8, HW_ = 16;                 // output tile
+constexpr int PH = HT + 2, PW = HW_ + 2;        // patch
+constexpr int CK = 32, LDC = CK + 8;            // channel chunk, LDS row stride (bf16 elements)
+
+template <int TM, int TN, int WM, int WN, bool SPLIT>
+__global__ __launch_bounds__(256) void conv3x3_halo_bf16(GemmArgs p) {
+  constexpr int BN = WN * TN * 32;
+  static_assert(WM * TM == 4 && WM * WN == 4, "128 output pixels, four waves");
+  constexpr int NP = PH * PW;                         // 180 patch pixels
+  constexpr int NPF = (NP * 8 + 255) / 256;            // float4 per thread per chunk
+  constexpr int NWF = (3 * BN * 4 + 255) / 256;        // 16-B weight pieces per thread per stage (3 taps)
+  __shared__ __attribute__((aligned(16))) unsigned short lds[(NP + 3 * BN) * LDC * (SPLIT ? 2 : 1)];
+  unsigned short* Ph = lds;
+  unsigned short* Wh = Ph + NP * LDC;
+  unsigned short* Pl = Wh + 3 * BN * LDC;
+  unsigned short* Wl = Pl + (SPLIT ? NP * LDC : 0);
+
+  const int t = threadIdx.x;
+  const int tiles_x = (p.Wo + HW_ - 1) / HW_, tiles_y = (p.Ho + HT - 1) / HT;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int b = blockIdx.x;
+  const int tn = b % tiles_n; b /= tiles_n;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const long long img = b / tiles_y;
+  const int y0 = ty * HT, x0 = tx * HW_, n0 = tn * BN;
+  const float* in = p.A + img * (long long)p.H * p.Wd * p.Cin;
+
+  // patch loader state: pixel / quad of each of this thread's float4
+  long long poff[NPF];
+  bool pok[NPF];
+  int plds[NPF];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int f = t + 256 * i;
+    const int pp = f >> 3, q = f & 7;
+    const int py = pp / PW, px = pp - py * PW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    pok[i] = pp < NP && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.Wd;
+    poff[i] = ((long long)gy * p.Wd + gx) * p.Cin + q * 4;
+    plds[i] = pp < NP ? pp * LDC + q * 4 : -1;
+  }
+  // weight loader state
+  long long woff[NWF];
+  int wlds[NWF];
+#pragma unroll
+  for (int i = 0; i < NWF; ++i) {
+    const int u = t + 256 * i;
+    const int row = u >> 2, part = u & 3;
+    const int tl = row / BN, n = row - tl * BN;
+    const bool ok = row < 3 * BN && n0 + n < p.N;
+    woff[i] = ok ? (long long)(n0 + n) * p.ldw + (long long)tl * p.Cin + part * 8 : -1;
+    wlds[i] = row < 3 * BN ? row * LDC + part * 8 : -1;
+  }
+
+  f32x4 rp[NPF];
+  uint4 rwh[NWF], rwl[NWF];
+  auto load_patch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      rp[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (pok[i]) rp[i] = *reinterpret_cast<const f32x4*>(in + poff[i] + c0);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      if (plds[i] >= 0) {
+        uint2 hi, lo;
+        split4(rp[i], hi, lo);
+        *reinterpret_cast<uint2*>(&Ph[plds[i]]) = hi;
+        if (SPLIT) *reinterpret_cast<uint2*>(&Pl[plds[i]]) = lo;
+      }
+    }
+  };
+  auto load_w = [&](int c0, int kh) {
+    const long long base = (long long)kh * 3 * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < NWF; ++i) {
+      rwh[i] = make_uint4(0u, 0u, 0u, 0u);
+      rwl[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (woff[i] >= 0) {
+        rwh[i] = *reinterpret_cast<const uint4*>(p.Whi + woff[i] + base);
+        if (SPLIT) rwl[i] = *reinterpret_cast<const uint4*>(p.Wlo + woff[i] + base);
+      }
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < NWF; ++i) {
+      if (wlds[i] >= 0) {
+        *reinterpret_cast<uint4*>(&Wh[wlds[i]]) = rwh[i];
+        if (SPLIT) *reinterpret_cast<uint4*>(&Wl[wlds[i]]) = rwl[i];
+      }
+    }
+  };
+
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  int arow[TM];  // patch index of this lane's output pixel (tap 0,0) per 32-row block
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = (wm * TM + i) * 32 + r;
+    arow[i] = (m / HW_) * PW + (m % HW_);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nchunk = p.Cin / CK;
+  load_patch(0);
+  load_w(0, 0);
+  for (int c = 0; c < nchunk; ++c) {
+    store_patch();
+    if (c + 1 < nchunk) load_patch((c + 1) * CK);
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+      store_w();
+      __syncthreads();
+      if (kh < 2) load_w(c * CK, kh + 1);
+      else if (c + 1 < nchunk) load_w((c + 1) * CK, 0);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+        for (int ks = 0; ks < CK / 16; ++ks) {
+          bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int o = (arow[i] + kh * PW + kw) * LDC + ks * 16 + h * 8;
+            ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Ph[o]));
+            if (SPLIT) al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Pl[o]));
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int o = (kw * BN + (wn * TN + j) * 32 + r) * LDC + ks * 16 + h * 8;
+            bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Wh[o]));
+            if (SPLIT) bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Wl[o]));
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (SPLIT) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+              }
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  float* outb = p.C + img * (long long)p.Ho * p.Wo * p.ldc;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + r;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int y = y0 + m / HW_, x = x0 + m % HW_;
+        if (y < p.Ho && x < p.Wo) outb[((long long)y * p.Wo + x) * p.ldc + n] = mvt_act(acc[i][j][e] + bv, p.act);
+      }
+    }
+  }
+}
+
+template <bool SPLIT>
+int launch_conv3x3_halo(const GemmArgs& a, int nimg, hipStream_t s) {
+  const long long tiles = (long long)nimg * mvt_cdiv(a.Ho, HT) * mvt_cdiv(a.Wo, HW_);
+  if (a.N % 128 != 0 && a.N % 96 == 0) {
+    hipLaunchKernelGGL((conv3x3_halo_bf16<1, 3, 4, 1, SPLIT>), dim3((unsigned)(tiles * mvt_cdiv(a.N, 96))), dim3(256), 0, s, a);
+  } else if (a.N <= 64) {
+    hipLaunchKernelGGL((conv3x3_halo_bf16<1, 2, 4, 1, SPLIT>), dim3((unsigned)(tiles * mvt_cdiv(a.N, 64))), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((conv3x3_halo_bf16<2, 2, 2, 2, SPLIT>), dim3((unsigned)(tiles * mvt_cdiv(a.N, 128))), dim3(256), 0, s, a);
+  }
+  return mvt_launch_status();
+}
+
 inline int pick_tile(const GemmArgs& a);
 
 template <bool SPLIT>
@@ -546,5 +745,7 @@ extern "C" int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, con
   a.nk = (a.K + BKB - 1) / BKB;
   a.ldw = a.nk * BKB;  // weights are [Cout][round_up(K, 64)], zero padded
   a.lda = 0;
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0 && (long long)n * mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4 < (1LL << 31))
+    return wt_lo ? launch_conv3x3_halo<true>(a, n, mvt_stream(stream)) : launch_conv3x3_halo<false>(a, n, mvt_stream(stream));
   return wt_lo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));
 }

@@ -86,7 +86,8 @@ def test_gemm(hip, M, N, K, act, res, prec):
 
 CONVS = [  # n, H, W, Cin, Cout, k, stride, pad
     (2, 64, 96, 3, 64, 7, 2, 3), (2, 33, 47, 64, 64, 3, 1, 1), (1, 33, 47, 64, 96, 3, 2, 1), (2, 30, 30, 96, 128, 1, 2, 0),
-    (1, 16, 24, 416, 256, 3, 1, 1), (3, 9, 11, 256, 128, 1, 1, 0), (1, 20, 20, 128, 128, 3, 2, 1)]
+    (1, 16, 24, 416, 256, 3, 1, 1), (3, 9, 11, 256, 128, 1, 1, 0), (1, 20, 20, 128, 128, 3, 2, 1), (1, 20, 37, 96, 96, 3, 1, 1),
+    (2, 17, 16, 128, 128, 3, 1, 1), (1, 8, 16, 64, 64, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
