@@ -88,6 +88,15 @@ int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, const unsigned
                     float* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
                     int act, void* stream);
 
+/* Fused transformer MLP on the bf16 matrix cores, in place:
+ *   x[m][0:C] += W2 . gelu_tanh(W1 . LayerNorm(x[m][0:C]) + b1) + b2      (LayerNorm without affine, given eps)
+ * (AttnBlock / CrossAttnBlock second half, cotracker2/blocks.py:299-300, 336-337).  w1 [H][ldw1] and
+ * w2 [C][ldw2] are bf16 (mvt_split_bf16 hi parts); C == 256, H % 64 == 0.  The hidden activations stay in
+ * registers (the first GEMM's accumulator is the second GEMM's operand). */
+int mvt_mlp_fused_bf16(float* x, int ldx, const unsigned short* w1, int ldw1, const float* b1,
+                       const unsigned short* w2, int ldw2, const float* b2, long long M, int C, int H, float eps,
+                       void* stream);
+
 /* rgbs [V][T][3][H][W] (values 0..255) -> x [T_sel][V][H][W][4] = (2*(rgb/255)-1, 0) for frames
  * t0..t0+nt-1 (mvtracker.py:565-567 normalisation + channels-last repack). */
 int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream);

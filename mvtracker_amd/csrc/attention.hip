@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void attention_qlane_kernel(const float* __res
     }
     const float s = ((s0 + s1) + (s2 + s3)) * scale;
     const float mn = fmaxf(m, s);
-    const float corr = expf(m - mn);
-    const float p = expf(s - mn);
+    const float corr = __expf(m - mn);
+    const float p = __expf(s - mn);
     l = l * corr + p;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void attention_klane_kernel(const float* __res
     }
     const float s = ((s0 + s1) + (s2 + s3)) * scale;
     const float mn = fmaxf(m, s);
-    const float corr = expf(m - mn);  // exp(-inf) = 0 on the first key
-    const float p = expf(s - mn);
+    const float corr = __expf(m - mn);  // exp(-inf) = 0 on the first key
+    const float p = __expf(s - mn);
     l = l * corr + p;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void attention_klane_kernel(const float* __res
   }
   // merge the 64 lane states through LDS
   const float M = wave_max(m);
-  const float w = (m == -INFINITY) ? 0.f : expf(m - M);
+  const float w = (m == -INFINITY) ? 0.f : __expf(m - M);
   const float L = wave_sum(l * w);
   float* r = red[wave];
 #pragma unroll
@@ -242,13 +242,13 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_ukeys_kerne
       const float sc = (s0 + s1) + (s2 + s3);
       if (__ballot(sc > m)) {  // some lane has a new running maximum: rescale (rare after the first keys)
         const float mn = fmaxf(m, sc);
-        const float corr = expf(m - mn);
+        const float corr = __expf(m - mn);
         l *= corr;
 #pragma unroll
         for (int d = 0; d < DH; ++d) acc[d] *= corr;
         m = mn;
       }
-      const float p = expf(sc - m);
+      const float p = __expf(sc - m);
       l += p;
 #pragma unroll
       for (int d = 0; d < Q4; ++d) {
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_ukeys_kerne
       const float* r = lds + (w * 64 + lane) * (DH + 2);
       const float mw = r[0];
       const float mn = fmaxf(m, mw);
-      const float ca = (m == -INFINITY) ? 0.f : expf(m - mn);
-      const float cb = (mw == -INFINITY) ? 0.f : expf(mw - mn);
+      const float ca = (m == -INFINITY) ? 0.f : __expf(m - mn);
+      const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
       l = l * ca + r[1] * cb;
 #pragma unroll
       for (int d = 0; d < DH; ++d) acc[d] = acc[d] * ca + r[2 + d] * cb;

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mvt_split_bf16": [P, P, P, LL, P],
     "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "mvt_mlp_fused_bf16": [P, I, P, I, P, P, I, P, LL, I, I, F, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
     "mvt_instnorm_stats": [P, I, P, P, I, LL, I, P],
@@ -127,6 +128,10 @@ def gemm_bf16(A, lda, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NON
 def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE):
     _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
           ldo, act, _stream())
+
+
+def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
+    _call("mvt_mlp_fused_bf16", _ptr(x), ldx, _ptr(w1), ldw1, _ptr(b1), _ptr(w2), ldw2, _ptr(b2), M, Cc, H, eps, _stream())
 
 
 def rgb_to_nhwc4(rgbs, out, V, T, H, W, t0, nt):

@@ -104,6 +104,7 @@ class MVTracker(nn.Module):
         #   "bf16x3" split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi), fp32-grade results, ~5x the fp32 MFMA rate
         #   "bf16"   operands rounded to bf16, fp32 accumulate (the arithmetic of torch autocast in the reference demo)
         self.precision = os.environ.get("MVT_PRECISION", "fp32")
+        self.fuse_mlp = True
         d = self.updateformer_input_dim
         self._time_embed_host = self._make_time_embed(self.S, d)
 
@@ -366,6 +367,10 @@ class MVTracker(nn.Module):
 
     def _mlp_residual(self, pk, p, tok, rows, xn, hbuf):
         h = self.hidden
+        w1, w2 = pk[p + ".mlp.fc1"], pk[p + ".mlp.fc2"]
+        if self.precision == "bf16" and h == 256 and self.fuse_mlp and rows >= 4096:  # LN + fc1 + GELU + fc2 + residual in one kernel
+            hip.mlp_fused_bf16(tok, h, w1[0][0], w1[0][0].shape[1], w1[1], w2[0][0], w2[0][0].shape[1], w2[1], rows, h, 4 * h, 1e-6)
+            return
         hip.layernorm(tok, h, None, None, xn, h, rows, h, 1e-6)
         self._lin(pk, p + ".mlp.fc1", xn, h, rows, hbuf, 4 * h, hip.ACT_GELU_TANH)
         self._lin(pk, p + ".mlp.fc2", hbuf, 4 * h, rows, tok, h, R=tok, ldr=h)

@@ -129,6 +129,29 @@ def test_split_bf16(hip):
     assert torch.equal(lo.cpu().view(torch.bfloat16), (x - h.float()).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("M", [128, 1000, 13056])
+def test_mlp_fused_bf16(hip, M):
+    g = torch.Generator().manual_seed(M)
+    C, H = 256, 1024
+    x = torch.randn(M, C, generator=g) * 2 + 0.3
+    W1 = torch.randn(H, C, generator=g) / 16
+    b1 = torch.randn(H, generator=g) * 0.1
+    W2 = torch.randn(C, H, generator=g) / 32
+    b2 = torch.randn(C, generator=g) * 0.1
+    h1, _ = split(hip, G(W1), False)
+    h2, _ = split(hip, G(W2), False)
+    xg = G(x)
+    hip.mlp_fused_bf16(xg, C, h1, C, G(b1), h2, H, G(b2), M, C, H, 1e-6)
+    torch.cuda.synchronize()
+    bf = lambda t: t.to(torch.bfloat16).double()
+    ln = F.layer_norm(x.double(), (C,), None, None, 1e-6)
+    hid = F.gelu(bf(ln.float()) @ bf(W1).t() + b1.double(), approximate="tanh")
+    ref = x.double() + bf(hid.float()) @ bf(W2).t() + b2.double()
+    assert rel_err(xg, ref) < 2e-3  # bf16 operands; the hidden tile is re-rounded to bf16 between the two GEMMs
+    exact = x.double() + F.gelu(ln @ W1.double().t() + b1.double(), approximate="tanh") @ W2.double().t() + b2.double()
+    assert rel_err(xg, exact) < 2e-2
+
+
 def test_conv2d_rejects_bad_args(hip):
     x = torch.zeros(1, 8, 8, 48, device=DEV)
     with pytest.raises(hip.HipError):
