@@ -88,6 +88,14 @@ int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, const unsigned
                     float* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
                     int act, void* stream);
 
+/* mvt_gemm_bf16 with LayerNorm (biased variance, eps, optional affine ln_w / ln_b of length K) applied to every A
+ * row on the fly: C = R + act(LayerNorm(A) . W^T + bias).  K % 4 == 0, K <= 1024.  Replaces the norm1 / norm_context
+ * + to_q / to_kv pairs of AttnBlock / CrossAttnBlock (cotracker2/blocks.py:298, 335) without materialising the
+ * normalised tokens. */
+int mvt_ln_gemm_bf16(const float* A, int lda, const float* ln_w, const float* ln_b, float ln_eps,
+                     const unsigned short* w_hi, const unsigned short* w_lo, int ldw, const float* bias, const float* R,
+                     int ldr, float* C, int ldc, int M, int N, int K, int act, void* stream);
+
 /* Fused transformer MLP on the bf16 matrix cores, in place:
  *   x[m][0:C] += W2 . gelu_tanh(W1 . LayerNorm(x[m][0:C]) + b1) + b2      (LayerNorm without affine, given eps)
  * (AttnBlock / CrossAttnBlock second half, cotracker2/blocks.py:299-300, 336-337).  w1 [H][ldw1] and

@@ -31,6 +31,11 @@ struct GemmArgs {
   int nk;  // number of k tiles (32 wide for the fp32 kernel, 64 wide for the bf16 kernels)
   const unsigned short* Whi;  // bf16 kernels: weights pre-split into bf16 hi (+ lo for the split-precision mode)
   const unsigned short* Wlo;
+  // optional LayerNorm fused into the A loader of the dense bf16 kernels (K <= 1024): a = (a - mean) * rstd [* w + b]
+  int ln;
+  float ln_eps;
+  const float* ln_w;
+  const float* ln_b;
 };
 
 constexpr int BK = 32;
@@ -272,6 +277,41 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
   }
   const int kp4 = (p.K + 3) & ~3;
 
+  // fused LayerNorm: per-row mean / rstd over the K columns.  A row of a k-tile is spread over the 16 threads that
+  // share rbase (lane bits 0-3), so one xor-shuffle tree per row finishes the sums; the tile is read again (L2) below.
+  float ln_mean[AF], ln_rstd[AF];
+  if (p.ln) {
+    float s1[AF], s2[AF];
+#pragma unroll
+    for (int i = 0; i < AF; ++i) s1[i] = s2[i] = 0.f;
+    for (int kt = 0; kt < p.nk; ++kt) {
+      const bool kok = kt * BKB + c4 * 4 < kp4;
+#pragma unroll
+      for (int i = 0; i < AF; ++i) {
+        if (kok && a_hw[i]) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BKB);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool in = kt * BKB + c4 * 4 + e < p.K;
+            s1[i] += in ? v[e] : 0.f;
+            s2[i] += in ? v[e] * v[e] : 0.f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < AF; ++i) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        s1[i] += __shfl_xor(s1[i], o, 64);
+        s2[i] += __shfl_xor(s2[i], o, 64);
+      }
+      ln_mean[i] = s1[i] / (float)p.K;
+      const float var = fmaxf(s2[i] / (float)p.K - ln_mean[i] * ln_mean[i], 0.f);
+      ln_rstd[i] = 1.0f / sqrtf(var + p.ln_eps);
+    }
+  }
+
   f32x4 ra[AF];
   uint2 rbh[BF], rbl[BF];
   auto load_tile = [&](int kt) {
@@ -282,6 +322,17 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
       for (int i = 0; i < AF; ++i) {
         ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (kok && a_hw[i]) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BKB);
+      }
+      if (p.ln && kok) {
+        f32x4 w4 = (f32x4){1.f, 1.f, 1.f, 1.f}, b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.ln_w) {
+          w4 = *reinterpret_cast<const f32x4*>(p.ln_w + k);
+          b4 = *reinterpret_cast<const f32x4*>(p.ln_b + k);
+        }
+#pragma unroll
+        for (int i = 0; i < AF; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[i][e] = (k + e < p.K && a_hw[i]) ? (ra[i][e] - ln_mean[i]) * ln_rstd[i] * w4[e] + b4[e] : 0.f;
       }
     } else if (p.mode == 1) {
       const int tap = k / p.Cin;
@@ -748,4 +799,22 @@ extern "C" int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, con
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0 && (long long)n * mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4 < (1LL << 31))
     return wt_lo ? launch_conv3x3_halo<true>(a, n, mvt_stream(stream)) : launch_conv3x3_halo<false>(a, n, mvt_stream(stream));
   return wt_lo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));
+}
+
+extern "C" int mvt_ln_gemm_bf16(const float* A, int lda, const float* ln_w, const float* ln_b, float ln_eps,
+                                const unsigned short* Whi, const unsigned short* Wlo, int ldw, const float* bias, const float* R,
+                                int ldr, float* C, int ldc, int M, int N, int K, int act, void* stream) {
+  MVT_REQUIRE(A && Whi && C && M > 0 && N > 0 && K > 0 && K % 4 == 0 && K <= 1024);
+  MVT_REQUIRE((ln_w == nullptr) == (ln_b == nullptr) && ((uintptr_t)ln_w % 16 == 0) && ((uintptr_t)ln_b % 16 == 0));
+  MVT_REQUIRE(lda % 4 == 0 && lda >= K);
+  MVT_REQUIRE(ldw % 64 == 0 && ldw >= ((K + 63) & ~63) && ldc >= N && (!R || ldr >= N));
+  MVT_REQUIRE(act >= 0 && act <= 3);
+  MVT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)Whi % 8 == 0) && ((uintptr_t)Wlo % 8 == 0));
+  GemmArgs a{};
+  a.A = A; a.Whi = Whi; a.Wlo = Wlo; a.bias = bias; a.R = R; a.C = C;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.act = act;
+  a.mode = 0;
+  a.nk = (K + BKB - 1) / BKB;
+  a.ln = 1; a.ln_eps = ln_eps; a.ln_w = ln_w; a.ln_b = ln_b;
+  return Wlo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));
 }

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mvt_split_bf16": [P, P, P, LL, P],
     "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "mvt_ln_gemm_bf16": [P, I, P, P, F, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_mlp_fused_bf16": [P, I, P, I, P, P, I, P, LL, I, I, F, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
@@ -128,6 +129,11 @@ def gemm_bf16(A, lda, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NON
 def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE):
     _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
           ldo, act, _stream())
+
+
+def ln_gemm_bf16(A, lda, ln_w, ln_b, eps, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NONE):
+    _call("mvt_ln_gemm_bf16", _ptr(A), lda, _ptr(ln_w), _ptr(ln_b), eps, _ptr(Whi), _ptr(Wlo), ldw, _ptr(bias), _ptr(R), ldr,
+          _ptr(Cm), ldc, M, N, K, act, _stream())
 
 
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):

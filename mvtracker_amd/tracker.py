@@ -105,6 +105,7 @@ class MVTracker(nn.Module):
         #   "bf16"   operands rounded to bf16, fp32 accumulate (the arithmetic of torch autocast in the reference demo)
         self.precision = os.environ.get("MVT_PRECISION", "fp32")
         self.fuse_mlp = True
+        self.fuse_ln = False
         d = self.updateformer_input_dim
         self._time_embed_host = self._make_time_embed(self.S, d)
 
@@ -365,14 +366,24 @@ class MVTracker(nn.Module):
         else:
             hip.gemm(A, lda, wp, wp.shape[1], b, R, ldr, out, ldc, M, n, k, act)
 
+    def _ln_lin(self, pk, name, x, rows, out, ldc, scratch, ln_w=None, ln_b=None, eps=1e-6, act=hip.ACT_NONE):
+        """out = act(LayerNorm(x) @ W^T + b).  mvt_ln_gemm_bf16 (LayerNorm inside the GEMM's A loader) exists but measured
+        slower than the separate 7 us LayerNorm pass + GEMM (every column tile recomputes the row statistics), so it is off."""
+        h = self.hidden
+        wp, b, n, k = pk[name]
+        if isinstance(wp, tuple) and self.fuse_ln:
+            hip.ln_gemm_bf16(x, h, ln_w, ln_b, eps, wp[0], wp[1], wp[0].shape[1], b, None, 0, out, ldc, rows, n, k, act)
+            return
+        hip.layernorm(x, h, ln_w, ln_b, scratch, h, rows, h, eps)
+        self._lin(pk, name, scratch, h, rows, out, ldc, act)
+
     def _mlp_residual(self, pk, p, tok, rows, xn, hbuf):
         h = self.hidden
         w1, w2 = pk[p + ".mlp.fc1"], pk[p + ".mlp.fc2"]
         if self.precision == "bf16" and h == 256 and self.fuse_mlp and rows >= 4096:  # LN + fc1 + GELU + fc2 + residual in one kernel
             hip.mlp_fused_bf16(tok, h, w1[0][0], w1[0][0].shape[1], w1[1], w2[0][0], w2[0][0].shape[1], w2[1], rows, h, 4 * h, 1e-6)
             return
-        hip.layernorm(tok, h, None, None, xn, h, rows, h, 1e-6)
-        self._lin(pk, p + ".mlp.fc1", xn, h, rows, hbuf, 4 * h, hip.ACT_GELU_TANH)
+        self._ln_lin(pk, p + ".mlp.fc1", tok, rows, hbuf, 4 * h, xn, act=hip.ACT_GELU_TANH)
         self._lin(pk, p + ".mlp.fc2", hbuf, 4 * h, rows, tok, h, R=tok, ldr=h)
 
     def _update_former(self, pk, x, ldx, n, delta, ldd):
@@ -383,7 +394,6 @@ class MVTracker(nn.Module):
         M = Mp + Mv
         tok = torch.empty(M, h, device=dev)
         xn = torch.empty(M, h, device=dev)
-        ctx = torch.empty(M, h, device=dev)
         qkv = torch.empty(M, 3 * inner, device=dev)
         att = torch.empty(M, inner, device=dev)
         hbuf = torch.empty(M, 4 * h, device=dev)
@@ -394,35 +404,29 @@ class MVTracker(nn.Module):
         for i in range(self.depth):
             # time attention over the S frames of every (point or virtual) track
             p = f"{u}time_blocks.{i}"
-            hip.layernorm(tok, h, None, None, xn, h, M, h, 1e-6)
-            self._lin(pk, p + ".attn.qkv", xn, h, M, qkv, 3 * inner)
+            self._ln_lin(pk, p + ".attn.qkv", tok, M, qkv, 3 * inner, xn)
             hip.attention(qkv, 3 * inner, S, 1, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, S, 1, att, inner, n + nv, S, S, H, dh)
             self._lin(pk, p + ".attn.to_out", att, inner, M, tok, h, R=tok, ldr=h)
             self._mlp_residual(pk, p, tok, M, xn, hbuf)
             # virtual <- point cross attention, per frame (row of item j in frame t is j*S + t)
             p = f"{u}space_virtual2point_blocks.{i}"
-            hip.layernorm(vt, h, None, None, xn[Mp:], h, Mv, h, 1e-6)
-            hip.layernorm(pt, h, *pk[p + ".norm_context"], ctx[:Mp], h, Mp, h, 1e-5)
-            self._lin(pk, p + ".cross_attn.to_q", xn[Mp:], h, Mv, qkv[Mp:], 3 * inner)
-            self._lin(pk, p + ".cross_attn.to_kv", ctx[:Mp], h, Mp, qkv[:Mp, inner:], 3 * inner)
+            self._ln_lin(pk, p + ".cross_attn.to_q", vt, Mv, qkv[Mp:], 3 * inner, xn[Mp:])
+            self._ln_lin(pk, p + ".cross_attn.to_kv", pt, Mp, qkv[:Mp, inner:], 3 * inner, xn[:Mp], *pk[p + ".norm_context"], eps=1e-5)
             hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, n, H,
                           dh)
             self._lin(pk, p + ".cross_attn.to_out", att[Mp:], inner, Mv, vt, h, R=vt, ldr=h)
             self._mlp_residual(pk, p, vt, Mv, xn[Mp:], hbuf[Mp:])
             # virtual self attention, per frame
             p = f"{u}space_virtual_blocks.{i}"
-            hip.layernorm(vt, h, None, None, xn[Mp:], h, Mv, h, 1e-6)
-            self._lin(pk, p + ".attn.qkv", xn[Mp:], h, Mv, qkv[Mp:], 3 * inner)
+            self._ln_lin(pk, p + ".attn.qkv", vt, Mv, qkv[Mp:], 3 * inner, xn[Mp:])
             hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, nv, H,
                           dh)
             self._lin(pk, p + ".attn.to_out", att[Mp:], inner, Mv, vt, h, R=vt, ldr=h)
             self._mlp_residual(pk, p, vt, Mv, xn[Mp:], hbuf[Mp:])
             # point <- virtual cross attention, per frame
             p = f"{u}space_point2virtual_blocks.{i}"
-            hip.layernorm(pt, h, None, None, xn[:Mp], h, Mp, h, 1e-6)
-            hip.layernorm(vt, h, *pk[p + ".norm_context"], ctx[Mp:], h, Mv, h, 1e-5)
-            self._lin(pk, p + ".cross_attn.to_q", xn[:Mp], h, Mp, qkv[:Mp], 3 * inner)
-            self._lin(pk, p + ".cross_attn.to_kv", ctx[Mp:], h, Mv, qkv[Mp:, inner:], 3 * inner)
+            self._ln_lin(pk, p + ".cross_attn.to_q", pt, Mp, qkv[:Mp], 3 * inner, xn[:Mp])
+            self._ln_lin(pk, p + ".cross_attn.to_kv", vt, Mv, qkv[Mp:, inner:], 3 * inner, xn[Mp:], *pk[p + ".norm_context"], eps=1e-5)
             hip.attention(qkv[:Mp], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[:Mp], inner, S, n, nv, H,
                           dh)
             self._lin(pk, p + ".cross_attn.to_out", att[:Mp], inner, Mp, pt, h, R=pt, ldr=h)

@@ -69,6 +69,11 @@ def gemm_bf16(A, lda, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=0):
     _v(Cm, M, N, ldc).copy_(y)
 
 
+def ln_gemm_bf16(A, lda, ln_w, ln_b, eps, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=0):
+    a = F.layer_norm(_v(A, M, K, lda), (K,), ln_w, ln_b, eps).contiguous()
+    gemm_bf16(a, K, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act)
+
+
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
     xv = _v(x, M, Cc, ldx)
     W1 = torch.as_strided(w1, (H, ldw1), (ldw1, 1)).view(torch.bfloat16).float()[:, :Cc]
@@ -304,7 +309,7 @@ def install(monkeypatch):
     import sys
     from mvtracker_amd import hip
     me = sys.modules[__name__]
-    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
+    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_bf16 ln_gemm_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
                  "depth_subsample avgpool2 unproject knn_scan knn_merge corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

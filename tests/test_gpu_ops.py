@@ -129,6 +129,25 @@ def test_split_bf16(hip):
     assert torch.equal(lo.cpu().view(torch.bfloat16), (x - h.float()).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("M,N,K", [(1000, 864, 256), (130, 96, 128), (12288, 576, 256)])
+def test_ln_gemm_bf16(hip, M, N, K, affine, prec):
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g) * 2 + 0.5
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    lw = torch.randn(K, generator=g) if affine else None
+    lb = torch.randn(K, generator=g) if affine else None
+    ref = F.layer_norm(A.double(), (K,), lw.double() if affine else None, lb.double() if affine else None, 1e-5) @ W.double().t() + b.double()
+    Wp = G(pad_w(W))
+    hi, lo = split(hip, Wp, prec == "bf16x3")
+    C = torch.empty(M, N, device=DEV)
+    hip.ln_gemm_bf16(G(A), K, G(lw) if affine else None, G(lb) if affine else None, 1e-5, hi, lo, Wp.shape[1], G(b), None, 0, C, N, M, N, K, 0)
+    torch.cuda.synchronize()
+    assert rel_err(C, ref) < PREC_TOL[prec]
+
+
 @pytest.mark.parametrize("M", [128, 1000, 13056])
 def test_mlp_fused_bf16(hip, M):
     g = torch.Generator().manual_seed(M)

@@ -119,3 +119,16 @@ if "conv" in which:
         r["bf16"] = timeit(lambda: hip.conv2d_bf16(x, hi, None, b, out, n, Hh, Ww, Cin, Cout, k, k, s, p, Cout), iters=5, warm=1)
         fl = 2 * n * Ho * Wo * Cout * (k * k * (3 if Cin == 4 else Cin))
         print(f"conv n={n} {Hh}x{Ww} {Cin}->{Cout} k{k} s{s}: " + "  ".join(f"{kk} {v:.0f} us ({fl / v / 1e6:.0f} TF/s)" for kk, v in r.items()))
+
+if "lngemm" in which:
+    for (M, N, K) in ((13056, 864, 256), (12288, 288, 256), (12288, 576, 256), (768, 864, 256)):
+        A = torch.randn(M, K, device=dev)
+        W = torch.randn(N, K, device=dev) / math.sqrt(K)
+        b = torch.randn(N, device=dev)
+        Cm = torch.empty(M, N, device=dev)
+        xn = torch.empty_like(A)
+        hi, _ = split(W, False)
+        t_g = timeit(lambda: hip.gemm_bf16(A, K, hi, None, K, b, None, 0, Cm, N, M, N, K, 0))
+        t_l = timeit(lambda: hip.layernorm(A, K, None, None, xn, K, M, K, 1e-6))
+        t_f = timeit(lambda: hip.ln_gemm_bf16(A, K, None, None, 1e-6, hi, None, K, b, None, 0, Cm, N, M, N, K, 0))
+        print(f"M={M} N={N} K={K}: gemm {t_g:.1f} us, layernorm {t_l:.1f} us, ln_gemm {t_f:.1f} us")
