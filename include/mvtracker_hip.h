@@ -105,6 +105,32 @@ int mvt_mlp_fused_bf16(float* x, int ldx, const unsigned short* w1, int ldw1, co
                        const unsigned short* w2, int ldw2, const float* b2, long long M, int C, int H, float eps,
                        void* stream);
 
+/* Fused remainder of an AttnBlock / CrossAttnBlock on the bf16 matrix cores (cotracker2/blocks.py:297-300, 334-337),
+ * in place on the token rows x [M][ldx] (C == 256):
+ *     x += att . Wo^T + bo                                  (att [M][ldatt], Ko == 288 columns; att == NULL skips it)
+ *     x += W2 . gelu_tanh(W1 . LayerNorm(x) + b1) + b2      (LayerNorm eps 1e-6, no affine; H % 128 == 0, H <= 1024)
+ *     y_i = LayerNorm_i(x) . Wn_i^T + bn_i                  (n_next <= 2 follow-up projections: the q / kv / qkv
+ *                                                            of the blocks that consume x next)
+ * All weights bf16 in the fragment-major layout of mvt_pack_frag_bf16 (ldwo / ldw1 / ldw2 / next.ldw are ignored).
+ * One launch replaces GEMM, LayerNorm, GEMM, GEMM, LayerNorm, GEMM [, LayerNorm, GEMM]. */
+/* Row-major bf16 w [N][ld] -> fragment-major out [ceil(N/32)][K/16][64][8]: lane (r = l&31, h = l>>5) of fragment
+ * (nb, ks) holds w[nb*32 + r][ks*16 + 8h .. +7] (zero rows past N) -- the MFMA 32x32x16 A operand, one coalesced 1-KiB
+ * load per wave and k-step.  K % 16 == 0. */
+int mvt_pack_frag_bf16(const unsigned short* w, int ld, int N, int K, unsigned short* out, void* stream);
+typedef struct mvt_block_next {
+  const unsigned short* w; /* fragment-major bf16 of [N][256] */
+  const float* b;          /* [N] */
+  const float* lnw;        /* LayerNorm affine [256] or NULL (both) */
+  const float* lnb;
+  float* y;                /* [M][ldy] */
+  int ldw, N, ldy;
+  float eps;
+} mvt_block_next;
+int mvt_block_fused_bf16(float* x, int ldx, const float* att, int ldatt, int Ko, const unsigned short* wo, int ldwo,
+                         const float* bo, const unsigned short* w1, int ldw1, const float* b1, const unsigned short* w2,
+                         int ldw2, const float* b2, int H, const mvt_block_next* next, int n_next, long long M, int C,
+                         void* stream);
+
 /* rgbs [V][T][3][H][W] (values 0..255) -> x [T_sel][V][H][W][4] = (2*(rgb/255)-1, 0) for frames
  * t0..t0+nt-1 (mvtracker.py:565-567 normalisation + channels-last repack). */
 int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream);

@@ -1,0 +1,421 @@
+// Fused "rest of a transformer block" for the updater on the bf16 matrix cores (cotracker2/blocks.py:297-300,
+// 334-337): everything that follows the attention of an AttnBlock / CrossAttnBlock, in ONE kernel, in place:
+//     x += att . Wo^T + bo                                    (attention output projection + residual)
+//     x += W2 . gelu_tanh(W1 . LayerNorm(x) + b1) + b2        (MLP + residual)
+//     y  = LayerNorm(x)[* lnw + lnb] . Wn^T + bn              (optional: the NEXT block's q / kv / qkv projection)
+// Unfused this is 6-7 launches (GEMM, LayerNorm, GEMM, GEMM, LayerNorm, GEMM) whose intermediates round-trip through
+// HBM; for the 768 virtual-token rows each of them is pure launch / fill latency.
+//
+// Structure: a workgroup owns 128 token rows (four 32-row MFMA blocks) and runs 8 waves.  Activations live in LDS
+// as bf16 ([128][K+8] images, conflict-free ds_read_b128); every weight matrix is streamed from global / L2 exactly
+// once per workgroup, straight into MFMA A-operand registers (lane (r,h) reads 16 B of row n0+r at k0+8h: the eight
+// k-steps that share a 128-B line hit L1).  All GEMMs are computed transposed, out^T (n x m) = W (n x k) . act^T, so a
+// weight fragment feeds four MFMAs (the four token blocks) and the accumulator holds token m on the lane and
+// channel n in the registers: LayerNorm statistics are per-lane sums + one cross-wave exchange through LDS.
+//   out-proj / MLP-fc2 / next-proj : wave w owns output channel block(s) n = w (, w+8, ...) x 4 token blocks
+//   MLP-fc1 (per 128 hidden units) : wave (jb = w&3, mp = w>>2) owns hidden block jb x token blocks 2mp, 2mp+1;
+//                                    gelu(H) is written to LDS as bf16 [m][j] for fc2 (double buffered, one barrier
+//                                    per chunk)
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NT = 512;   // threads (8 waves)
+constexpr int C = 256;    // hidden size of the updater
+constexpr int LDX = C + 8;
+// NMB = 32-row token blocks per workgroup.  NMB = 4 (128 rows, MLP chunks of 128 hidden units) for the 12k point rows;
+// NMB = 1 (32 rows, chunks of 256) for the 768 virtual-token rows, where the kernel is pure weight streaming and the
+// work has to be spread over as many CUs as possible.
+template <int NMB> struct Cfg {
+  static constexpr int BM = 32 * NMB;
+  static constexpr int HC = NMB == 4 ? 128 : 256;       // MLP hidden units per chunk
+  static constexpr int JW = HC / 32;                     // waves across the hidden blocks of a chunk (4 or 8)
+  static constexpr int NM1 = NMB / (8 / JW);             // token blocks per wave in fc1 (2 or 1)
+  static constexpr int LDH = NMB == 4 ? 152 : HC + 8;    // bf16 row stride of the H buffers
+  static constexpr int LDA = 296;                        // attention tile row stride (Ko = 288)
+  static_assert(BM * LDA <= 2 * BM * LDH, "attention tile fits the H buffers");
+};
+constexpr int FS = 512;   // elements per (32-row block, k-step) weight fragment: [64 lanes][8 bf16], see mvt_pack_frag_bf16
+
+struct BlockArgs {
+  float* x;                  // [M][ldx] tokens, updated in place
+  int ldx;
+  const float* att;          // [M][ldatt] attention output (Ko columns) or null: skip the output projection
+  int ldatt, Ko;
+  const unsigned short* wo;  // fragment-major bf16 (mvt_pack_frag_bf16) of [C][Ko]
+  const float* bo;
+  int ldwo;
+  const unsigned short* w1;  // fragment-major bf16 of [H][C]
+  const float* b1;
+  const unsigned short* w2;  // fragment-major bf16 of [C][H]
+  const float* b2;
+  int ldw1, ldw2, H;
+  mvt_block_next next[2];    // up to two follow-up projections of LayerNorm(x)
+  int n_next;
+  long long M;
+};
+
+__device__ __forceinline__ bf16x8 ldg_frag(const unsigned short* p) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned short* p) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+
+// acc[mb] += W[n0 + r][k] * Act[mb*32 + r'][k] for k in [0, 16*KS): W from global (wrow -> W[n0+r][8h]),
+// Act from LDS (arow -> Act[r][8h], row stride lda).  Weight fragments are fetched four k-steps ahead.
+template <int KS, int NMB>
+__device__ __forceinline__ void gemm_wt(f32x16 (&acc)[NMB], const unsigned short* wrow, const unsigned short* arow, int lda,
+                                        int mb0) {
+  constexpr int PF = (KS % 8 == 0) ? 8 : 4;
+  bf16x8 wq[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) wq[i] = ldg_frag(wrow + (i < KS ? i : 0) * FS);
+  // groups of four k-steps (rolled: a fully unrolled body makes the scheduler hoist every LDS read and spill)
+#pragma unroll 1
+  for (int g = 0; g < KS / PF; ++g) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int ks = g * PF + j;
+      const bf16x8 wa = wq[j];
+      wq[j] = ldg_frag(wrow + (ks + PF < KS ? ks + PF : KS - 1) * FS);
+#pragma unroll
+      for (int i = 0; i < NMB; ++i) {
+        const bf16x8 xb = lds_frag(arow + (mb0 + i) * 32 * lda + ks * 16);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[i], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KS % PF; ++j) {
+    const int ks = (KS / PF) * PF + j;
+#pragma unroll
+    for (int i = 0; i < NMB; ++i) {
+      const bf16x8 xb = lds_frag(arow + (mb0 + i) * 32 * lda + ks * 16);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[j], xb, acc[i], 0, 0, 0);
+    }
+  }
+}
+
+// Same product with a persistent weight-fragment queue: wq holds the first PFQ fragments of this stream on entry and the
+// first PFQ fragments of the NEXT stream (nxt -> its row, 8h already applied) on exit, so the global-load latency of
+// every GEMM call hides under the previous call instead of being exposed at its start.  KS % PFQ == 0.
+constexpr int PFQ = 8;
+template <int KS, int NMB>
+__device__ __forceinline__ void gemm_wq(f32x16 (&acc)[NMB], bf16x8 (&wq)[PFQ], const unsigned short* wrow, const unsigned short* nxt,
+                                        const unsigned short* arow, int lda, int mb0) {
+  static_assert(KS % PFQ == 0, "chained streams need whole groups");
+#pragma unroll 1
+  for (int g = 0; g < KS / PFQ; ++g) {
+#pragma unroll
+    for (int j = 0; j < PFQ; ++j) {
+      const int ks = g * PFQ + j;
+      const bf16x8 wa = wq[j];
+      wq[j] = ldg_frag(ks + PFQ < KS ? wrow + (ks + PFQ) * FS : nxt + (ks + PFQ - KS) * FS);
+#pragma unroll
+      for (int i = 0; i < NMB; ++i) {
+        const bf16x8 xb = lds_frag(arow + (mb0 + i) * 32 * lda + ks * 16);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[i], 0, 0, 0);
+      }
+    }
+  }
+}
+__device__ __forceinline__ void fill_wq(bf16x8 (&wq)[PFQ], const unsigned short* wrow) {
+#pragma unroll
+  for (int j = 0; j < PFQ; ++j) wq[j] = ldg_frag(wrow + j * FS);
+}
+
+// LayerNorm of the 128 x C tile held as accumulators v[4][16] (wave w: channels w*32 .. +31 of every token), written
+// as bf16 into Xs.  st: LDS scratch [8 waves][128 tokens][2].  Optional affine (wave's channel slice).
+template <int NMB>
+__device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short* Xs, float* st, int wave, int lane, float eps,
+                                          const float* lnw, const float* lnb) {
+  constexpr int BM = 32 * NMB;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s1 += v[mb][e];
+      s2 = fmaf(v[mb][e], v[mb][e], s2);
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (h == 0) {
+      st[(wave * BM + mb * 32 + r) * 2] = s1;
+      st[(wave * BM + mb * 32 + r) * 2 + 1] = s2;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      s1 += st[(w * BM + mb * 32 + r) * 2];
+      s2 += st[(w * BM + mb * 32 + r) * 2 + 1];
+    }
+    const float mean = s1 / (float)C;
+    const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)C - mean * mean, 0.f) + eps);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = wave * 32 + 8 * g + 4 * h;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (v[mb][4 * g + e] - mean) * rstd;
+        if (lnw) o[e] = o[e] * lnw[n + e] + lnb[n + e];
+      }
+      const bf16x4 b = __builtin_convertvector(o, bf16x4);
+      *reinterpret_cast<u32x2*>(&Xs[(mb * 32 + r) * LDX + n]) = __builtin_bit_cast(u32x2, b);
+    }
+  }
+  __syncthreads();
+}
+
+template <int NMB>
+__global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
+  using K_ = Cfg<NMB>;
+  constexpr int BM = K_::BM, HC = K_::HC, LDH = K_::LDH, LDA = K_::LDA;
+  __shared__ __attribute__((aligned(16))) unsigned short Xs[BM * LDX];
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[2][BM * LDH];
+  __shared__ float st[8 * BM * 2];
+  __shared__ float b1s[4 * C];
+
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const long long m0 = (long long)blockIdx.x * BM;
+  for (int i = t; i < p.H; i += NT) b1s[i] = p.b1[i];
+
+  // token values of this wave's 32-channel slice: v[mb][e] = x[m0 + mb*32 + r][wave*32 + (e&3) + 8*(e>>2) + 4h]
+  f32x16 v[NMB];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[mb][e] = 0.f;
+
+  // ---- 1. attention output projection (accumulated into v, x is added afterwards)
+  if (p.att) {
+    // att tile (fp32) -> bf16 [128][296], overlaid on the two (still unused) H buffers
+    unsigned short* As = &Hs[0][0];
+    const int q4 = p.Ko / 4;  // float4 per row
+    for (int f = t; f < BM * q4; f += NT) {
+      const int row = f / q4, c = (f - row * q4) * 4;
+      const long long m = m0 + row;
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < p.M) a = *reinterpret_cast<const f32x4*>(p.att + m * (long long)p.ldatt + c);
+      const bf16x4 b = __builtin_convertvector(a, bf16x4);
+      *reinterpret_cast<u32x2*>(&As[row * LDA + c]) = __builtin_bit_cast(u32x2, b);
+    }
+    __syncthreads();
+    gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[mb][e] += p.bo[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+  }
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb) {
+    const long long m = m0 + mb * 32 + r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < p.M) xv = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += xv[e];
+    }
+  }
+
+  // ---- 2. MLP: LayerNorm -> Xs, then chunks of 128 hidden units.  x (after the projection) is parked in global memory
+  //         during the chunk loop so that its 64 registers are free for the accumulators.
+  auto store_x = [&]() {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const long long m = m0 + mb * 32 + r;
+      if (m < p.M) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = v[mb][4 * g + e];
+          *reinterpret_cast<f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h) = o;
+        }
+      }
+    }
+  };
+  if (p.att) store_x();
+  ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
+  {
+    f32x16 acc2[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[mb][e] = 0.f;
+    constexpr int JW = K_::JW, NM1 = K_::NM1;
+    const int jb = wave % JW, mp = wave / JW;
+    const int nchunk = p.H / HC;
+    const unsigned short* w1row = p.w1 + ((long long)jb * (C / 16) * 64 + lane) * 8;                 // + c * 4 blocks
+    const unsigned short* w2row = p.w2 + ((long long)wave * (p.H / 16) * 64 + lane) * 8;             // + c * 8 k-steps
+    bf16x8 q1[PFQ], q2[PFQ];
+    fill_wq(q1, w1row);
+    fill_wq(q2, w2row);
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+      unsigned short* Hb = Hs[c & 1];
+      const int cn = c + 1 < nchunk ? c + 1 : c;  // the last chunk prefetches itself again (harmless)
+      // fc1: H^T block (hidden jb of this chunk) x token blocks 2mp, 2mp+1
+      f32x16 ha[NM1];
+#pragma unroll
+      for (int i = 0; i < NM1; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ha[i][e] = 0.f;
+      gemm_wq<C / 16, NM1>(ha, q1, w1row + (long long)c * JW * (C / 16) * FS, w1row + (long long)cn * JW * (C / 16) * FS, &Xs[r * LDX + 8 * h], LDX,
+                           NM1 * mp);
+#pragma unroll
+      for (int i = 0; i < NM1; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = mvt_gelu_tanh(ha[i][4 * g + e] + b1s[c * HC + jb * 32 + 8 * g + 4 * h + e]);
+          const bf16x4 b = __builtin_convertvector(o, bf16x4);
+          *reinterpret_cast<u32x2*>(&Hb[((NM1 * mp + i) * 32 + r) * LDH + jb * 32 + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, b);
+        }
+      }
+      __syncthreads();
+      // fc2 partial: out^T block (channels of this wave) += W2[:, chunk] . H^T
+      gemm_wq<HC / 16, NMB>(acc2, q2, w2row + (long long)c * (HC / 16) * FS, w2row + (long long)cn * (HC / 16) * FS, &Hb[r * LDH + 8 * h], LDH, 0);
+    }
+    // x = x (parked) + MLP output
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const long long m = m0 + mb * 32 + r;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) xv = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[mb][4 * g + e] = xv[e] + acc2[mb][4 * g + e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
+      }
+    }
+  }
+  store_x();
+
+  // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {  // static indices: a dynamically indexed kernel-argument array would live in scratch
+    if (q >= p.n_next) break;
+    const mvt_block_next nx = p.next[q];
+    __syncthreads();  // every wave is done reading Xs / Hs
+    {  // x is re-read (this thread stored it above) so that nothing but the accumulators is live during the GEMM
+      f32x16 xv[NMB];
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        const long long m = m0 + mb * 32 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 t4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (m < p.M) t4 = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[mb][4 * g + e] = t4[e];
+        }
+      }
+      ln_to_lds<NMB>(xv, Xs, st, wave, lane, nx.eps, nx.lnw, nx.lnb);
+    }
+    const int nblocks = (nx.N + 31) / 32;
+    auto nrow_of = [&](int nb) { return nx.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
+    bf16x8 qn[PFQ];
+    if (wave < nblocks) fill_wq(qn, nrow_of(wave));
+    for (int nb = wave; nb < nblocks; nb += 8) {
+      f32x16 acc[NMB];
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
+      gemm_wq<C / 16, NMB>(acc, qn, nrow_of(nb), nrow_of(nb + 8 < nblocks ? nb + 8 : nb), &Xs[r * LDX + 8 * h], LDX, 0);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        const long long m = m0 + mb * 32 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb * 32 + 8 * g + 4 * h;
+          if (n + 3 < nx.N) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[mb][4 * g + e] + nx.b[n + e];
+            *reinterpret_cast<f32x4*>(nx.y + m * (long long)nx.ldy + n) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < nx.N) nx.y[m * (long long)nx.ldy + n + e] = acc[mb][4 * g + e] + nx.b[n + e];
+          }
+        }
+      }
+    }
+  }
+}
+
+// [N][ld] row-major bf16 -> fragment-major [ceil(N/32)][K/16][64 lanes][8]: lane (r = l&31, h = l>>5) of fragment
+// (nb, ks) holds W[nb*32 + r][ks*16 + 8h .. +7] (zero rows past N), i.e. exactly the MFMA A operand, so that a wave
+// reads each fragment as one coalesced 1-KiB load and every byte of a cache line is consumed by a single instruction.
+__global__ void pack_frag_kernel(const unsigned short* __restrict__ w, int ld, int N, int K, unsigned short* __restrict__ out) {
+  const long long total = (long long)((N + 31) / 32) * (K / 16) * 64;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long long f = i >> 6;
+    const int ks = (int)(f % (K / 16));
+    const int nb = (int)(f / (K / 16));
+    const int n = nb * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5);
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (n < N) v = *reinterpret_cast<const u32x4*>(w + (long long)n * ld + k);
+    *reinterpret_cast<u32x4*>(out + i * 8) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int mvt_pack_frag_bf16(const unsigned short* w, int ld, int N, int K, unsigned short* out, void* stream) {
+  MVT_REQUIRE(w && out && N > 0 && K > 0 && K % 16 == 0 && ld % 8 == 0 && ld >= K);
+  MVT_REQUIRE(((uintptr_t)w % 16 == 0) && ((uintptr_t)out % 16 == 0));
+  const long long total = (long long)((N + 31) / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)mvt_cdiv(total, 256)), dim3(256), 0, mvt_stream(stream), w, ld, N, K, out);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_block_fused_bf16(float* x, int ldx, const float* att, int ldatt, int Ko, const unsigned short* wo, int ldwo,
+                                    const float* bo, const unsigned short* w1, int ldw1, const float* b1, const unsigned short* w2,
+                                    int ldw2, const float* b2, int H, const mvt_block_next* next, int n_next, long long M, int Cc,
+                                    void* stream) {
+  MVT_REQUIRE(x && w1 && b1 && w2 && b2 && M > 0 && Cc == C && H > 0 && H % 256 == 0 && H <= 4 * C);
+  MVT_REQUIRE(ldx % 4 == 0 && ldx >= C);
+  MVT_REQUIRE(!att || (wo && bo && Ko == 288 && ldatt % 4 == 0 && ldatt >= Ko));
+  MVT_REQUIRE(n_next >= 0 && n_next <= 2 && (n_next == 0 || next));
+  MVT_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)att % 16 == 0) && ((uintptr_t)wo % 16 == 0) && ((uintptr_t)w1 % 16 == 0) &&
+              ((uintptr_t)w2 % 16 == 0));
+  BlockArgs a{};
+  a.x = x; a.ldx = ldx; a.att = att; a.ldatt = ldatt; a.Ko = Ko; a.wo = wo; a.bo = bo; a.ldwo = ldwo;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.ldw1 = ldw1; a.ldw2 = ldw2; a.H = H; a.M = M; a.n_next = n_next;
+  for (int q = 0; q < n_next; ++q) {
+    const mvt_block_next& nx = next[q];
+    MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
+    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    a.next[q] = nx;
+  }
+  static const char* force = getenv("MVT_BLOCK_NMB");  // tuning override
+  const int nmb = force ? atoi(force) : (M >= 4096 ? 2 : 1);  // 64-row workgroups measured 1.6x faster than 128-row ones at M = 12288
+  if (nmb == 4)
+    hipLaunchKernelGGL(block_fused_bf16<4>, dim3((unsigned)mvt_cdiv(M, 128)), dim3(NT), 0, mvt_stream(stream), a);
+  else if (nmb == 2)
+    hipLaunchKernelGGL(block_fused_bf16<2>, dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
+  else
+    hipLaunchKernelGGL(block_fused_bf16<1>, dim3((unsigned)mvt_cdiv(M, 32)), dim3(NT), 0, mvt_stream(stream), a);
+  return mvt_launch_status();
+}

@@ -33,6 +33,8 @@ SIGNATURES = {
     "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "mvt_ln_gemm_bf16": [P, I, P, P, F, P, P, I, P, P, I, P, I, I, I, I, I, P],
+    "mvt_pack_frag_bf16": [P, I, I, I, P, P],
+    "mvt_block_fused_bf16": [P, I, P, I, I, P, I, P, P, I, P, P, I, P, I, P, I, LL, I, P],
     "mvt_mlp_fused_bf16": [P, I, P, I, P, P, I, P, LL, I, I, F, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
@@ -134,6 +136,26 @@ def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, 
 def ln_gemm_bf16(A, lda, ln_w, ln_b, eps, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NONE):
     _call("mvt_ln_gemm_bf16", _ptr(A), lda, _ptr(ln_w), _ptr(ln_b), eps, _ptr(Whi), _ptr(Wlo), ldw, _ptr(bias), _ptr(R), ldr,
           _ptr(Cm), ldc, M, N, K, act, _stream())
+
+
+def pack_frag_bf16(w, ld, N, K, out):
+    _call("mvt_pack_frag_bf16", _ptr(w), ld, N, K, _ptr(out), _stream())
+
+
+class BlockNext(C.Structure):
+    """mvt_block_next of include/mvtracker_hip.h."""
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("lnw", C.c_void_p), ("lnb", C.c_void_p), ("y", C.c_void_p),
+                ("ldw", C.c_int), ("N", C.c_int), ("ldy", C.c_int), ("eps", C.c_float)]
+
+
+def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw2, b2, H, nexts, M, Cc):
+    """nexts: list of dicts(w, ldw, b, N, lnw, lnb, eps, y, ldy) -- at most two follow-up projections."""
+    arr = (BlockNext * max(1, len(nexts)))()
+    for i, nx in enumerate(nexts):
+        arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],
+                           nx["ldy"], nx["eps"])
+    _call("mvt_block_fused_bf16", _ptr(x), ldx, _ptr(att), ldatt, Ko, _ptr(wo), ldwo, _ptr(bo), _ptr(w1), ldw1, _ptr(b1), _ptr(w2),
+          ldw2, _ptr(b2), H, C.cast(arr, C.c_void_p), len(nexts), M, Cc, _stream())
 
 
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):

@@ -105,6 +105,7 @@ class MVTracker(nn.Module):
         #   "bf16"   operands rounded to bf16, fp32 accumulate (the arithmetic of torch autocast in the reference demo)
         self.precision = os.environ.get("MVT_PRECISION", "fp32")
         self.fuse_mlp = True
+        self.fuse_blocks = True
         self.fuse_ln = False
         d = self.updateformer_input_dim
         self._time_embed_host = self._make_time_embed(self.S, d)
@@ -225,6 +226,11 @@ class MVTracker(nn.Module):
             b = sd[name + ".bias"] if b is None else b
             n, k = w.shape
             pk[name] = (matrix(w), b.contiguous(), n, k)
+            if prec == "bf16" and name.startswith("updateformer.") and k % 16 == 0 and "flow_head" not in name:
+                hi = pk[name][0][0]  # fragment-major copy for the fused block kernel
+                fr = torch.empty(_round_up(n, 32) * k, device=dev, dtype=torch.int16)
+                hip.pack_frag_bf16(hi, hi.shape[1], n, k, fr)
+                pk[name + "#frag"] = fr
 
         w = sd["fnet.conv1.weight"]  # (64,3,7,7) -> [64][7][32] with element kw*4+c
         st = torch.zeros(64, 7, 8, 4, device=dev)
@@ -387,6 +393,8 @@ class MVTracker(nn.Module):
         self._lin(pk, p + ".mlp.fc2", hbuf, 4 * h, rows, tok, h, R=tok, ldr=h)
 
     def _update_former(self, pk, x, ldx, n, delta, ldd):
+        if self.precision == "bf16" and self.hidden == 256 and self.num_heads * self.dim_head == 288 and self.fuse_blocks:
+            return self._update_former_fused(pk, x, ldx, n, delta, ldd)
         S, h, nv, H, dh = self.S, self.hidden, self.nv, self.num_heads, self.dim_head
         inner = H * dh
         dev = x.device
@@ -431,6 +439,73 @@ class MVTracker(nn.Module):
                           dh)
             self._lin(pk, p + ".cross_attn.to_out", att[:Mp], inner, Mp, pt, h, R=pt, ldr=h)
             self._mlp_residual(pk, p, pt, Mp, xn[:Mp], hbuf[:Mp])
+        od = self.out_dim
+        ldh = _round_up(od, 4)
+        h1 = torch.zeros(Mp, ldh, device=dev)
+        h2 = torch.zeros(Mp, ldh, device=dev)
+        self._lin(pk, u + "flow_head.0", pt, h, Mp, h1, ldh, hip.ACT_RELU)
+        self._lin(pk, u + "flow_head.2", h1, ldh, Mp, h2, ldh, hip.ACT_RELU)
+        self._lin(pk, u + "flow_head.4", h2, ldh, Mp, delta, ldd)
+
+    # ---- fused path (precision "bf16", hidden 256): per layer 4 attention launches + 5 fused block launches
+    def _fused_block(self, pk, p, attn_key, x, rows, att, nexts):
+        """x += att @ Wo^T + bo; x += MLP(LN(x)); then the follow-up projections of LN(x) listed in ``nexts``."""
+        h = self.hidden
+        no, n1, n2 = f"{p}.{attn_key}.to_out", p + ".mlp.fc1", p + ".mlp.fc2"
+        inner = self.num_heads * self.dim_head
+        hip.block_fused_bf16(x, h, att, inner, inner, pk[no + "#frag"], inner, pk[no][1], pk[n1 + "#frag"], h, pk[n1][1],
+                             pk[n2 + "#frag"], 4 * h, pk[n2][1], 4 * h, nexts, rows, h)
+
+    def _next(self, pk, name, y, ldy, ln=None, eps=1e-6):
+        _, b, n, k = pk[name]
+        d = dict(w=pk[name + "#frag"], ldw=k, b=b, N=n, y=y, ldy=ldy, eps=eps)
+        if ln is not None:
+            d.update(lnw=ln[0], lnb=ln[1])
+        return d
+
+    def _update_former_fused(self, pk, x, ldx, n, delta, ldd):
+        S, h, nv, H, dh = self.S, self.hidden, self.nv, self.num_heads, self.dim_head
+        inner = H * dh
+        dev = x.device
+        Mp, Mv = n * S, nv * S
+        M = Mp + Mv
+        tok = torch.empty(M, h, device=dev)
+        xn = torch.empty(M, h, device=dev)
+        qkv = torch.empty(M, 3 * inner, device=dev)   # time / virtual-self q|k|v; cross attention: q in [:, :inner], k|v in [:, inner:]
+        qp = torch.empty(Mp, inner, device=dev)       # point <- virtual queries (computed right after the time block)
+        att = torch.empty(M, inner, device=dev)
+        u = "updateformer."
+        self._lin(pk, u + "input_transform", x, ldx, Mp, tok, h)
+        hip.broadcast_rows(pk["virtual"], tok[Mp:], h, nv, S, h)
+        pt, vt = tok[:Mp], tok[Mp:]
+        self._ln_lin(pk, f"{u}time_blocks.0.attn.qkv", tok, M, qkv, 3 * inner, xn)
+        for i in range(self.depth):
+            tb, v2p = f"{u}time_blocks.{i}", f"{u}space_virtual2point_blocks.{i}"
+            vs, p2v = f"{u}space_virtual_blocks.{i}", f"{u}space_point2virtual_blocks.{i}"
+            last = i + 1 == self.depth
+            nxt_qkv = f"{u}time_blocks.{i + 1}.attn.qkv"
+            # time attention, then the rest of the time block; its epilogue already projects what the space blocks need
+            hip.attention(qkv, 3 * inner, S, 1, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, S, 1, att, inner, n + nv, S, S, H, dh)
+            self._fused_block(pk, tb, "attn", pt, Mp, att[:Mp],
+                              [self._next(pk, v2p + ".cross_attn.to_kv", qkv[:Mp, inner:], 3 * inner, pk[v2p + ".norm_context"], 1e-5),
+                               self._next(pk, p2v + ".cross_attn.to_q", qp, inner)])
+            self._fused_block(pk, tb, "attn", vt, Mv, att[Mp:], [self._next(pk, v2p + ".cross_attn.to_q", qkv[Mp:], 3 * inner)])
+            # virtual <- point
+            hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, n, H,
+                          dh)
+            self._fused_block(pk, v2p, "cross_attn", vt, Mv, att[Mp:], [self._next(pk, vs + ".attn.qkv", qkv[Mp:], 3 * inner)])
+            # virtual self attention
+            hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, nv, H,
+                          dh)
+            nx = [self._next(pk, p2v + ".cross_attn.to_kv", qkv[Mp:, inner:], 3 * inner, pk[p2v + ".norm_context"], 1e-5)]
+            # (the next time block's q|k|v of the virtual rows would overwrite the k|v just produced: it is projected
+            #  after the point <- virtual attention has consumed them, see below)
+            self._fused_block(pk, vs, "attn", vt, Mv, att[Mp:], nx)
+            # point <- virtual
+            hip.attention(qp, inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[:Mp], inner, S, n, nv, H, dh)
+            self._fused_block(pk, p2v, "cross_attn", pt, Mp, att[:Mp], [] if last else [self._next(pk, nxt_qkv, qkv[:Mp], 3 * inner)])
+            if not last:
+                self._ln_lin(pk, nxt_qkv, vt, Mv, qkv[Mp:], 3 * inner, xn[Mp:])
         od = self.out_dim
         ldh = _round_up(od, 4)
         h1 = torch.zeros(Mp, ldh, device=dev)

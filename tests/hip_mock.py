@@ -74,6 +74,30 @@ def ln_gemm_bf16(A, lda, ln_w, ln_b, eps, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, 
     gemm_bf16(a, K, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act)
 
 
+def pack_frag_bf16(w, ld, N, K, out):
+    nb = (N + 31) // 32
+    src = torch.zeros(nb * 32, K, dtype=torch.int16)
+    src[:N] = torch.as_strided(w, (N, K), (ld, 1))
+    out.reshape(-1)[:nb * 32 * K].copy_(src.reshape(nb, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1))
+
+
+def _unfrag(wf, N, K):
+    nb = (N + 31) // 32
+    return wf.reshape(-1)[:nb * 32 * K].reshape(nb, K // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(nb * 32, K)[:N].view(torch.bfloat16).float()
+
+
+def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw2, b2, H, nexts, M, Cc):
+    xv = _v(x, M, Cc, ldx)
+    if att is not None:
+        xv += _bf(_v(att, M, Ko, ldatt)) @ _unfrag(wo, Cc, Ko).t() + bo[:Cc]
+    hdn = F.gelu(_bf(F.layer_norm(xv, (Cc,), None, None, 1e-6)) @ _unfrag(w1, H, Cc).t() + b1[:H], approximate="tanh")
+    xv += _bf(hdn) @ _unfrag(w2, Cc, H).t() + b2[:Cc]
+    for nx in nexts:
+        Wn = _unfrag(nx["w"], nx["N"], Cc)
+        a = _bf(F.layer_norm(xv, (Cc,), nx.get("lnw"), nx.get("lnb"), nx["eps"]))
+        _v(nx["y"], M, nx["N"], nx["ldy"]).copy_(a @ Wn.t() + nx["b"][:nx["N"]])
+
+
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
     xv = _v(x, M, Cc, ldx)
     W1 = torch.as_strided(w1, (H, ldw1), (ldw1, 1)).view(torch.bfloat16).float()[:, :Cc]
@@ -309,7 +333,7 @@ def install(monkeypatch):
     import sys
     from mvtracker_amd import hip
     me = sys.modules[__name__]
-    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_bf16 ln_gemm_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
+    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_bf16 ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
                  "depth_subsample avgpool2 unproject knn_scan knn_merge corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

@@ -148,6 +148,52 @@ def test_ln_gemm_bf16(hip, M, N, K, affine, prec):
     assert rel_err(C, ref) < PREC_TOL[prec]
 
 
+@pytest.mark.parametrize("M,with_att,n_next", [(768, True, 2), (1000, True, 1), (12288, True, 2), (130, False, 0), (128, True, 0)])
+def test_block_fused_bf16(hip, M, with_att, n_next):
+    g = torch.Generator().manual_seed(M + n_next)
+    C, H, Ko = 256, 1024, 288
+    bf = lambda t: t.to(torch.bfloat16).double()
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.2
+    att = torch.randn(M, Ko, generator=g)
+    Wo, bo = torch.randn(C, Ko, generator=g) / 17, torch.randn(C, generator=g) * 0.1
+    W1, b1 = torch.randn(H, C, generator=g) / 16, torch.randn(H, generator=g) * 0.1
+    W2, b2 = torch.randn(C, H, generator=g) / 32, torch.randn(C, generator=g) * 0.1
+    Ns = [576, 864][:n_next]
+    Wn = [torch.randn(N, C, generator=g) / 16 for N in Ns]
+    bn = [torch.randn(N, generator=g) * 0.1 for N in Ns]
+    lnw, lnb = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.1
+    # reference (bf16 operands where the kernel rounds them, fp64 accumulation)
+    xr = x.double()
+    if with_att:
+        xr = xr + bf(att) @ bf(Wo).t() + bo.double()
+    hid = F.gelu(bf(F.layer_norm(xr, (C,), None, None, 1e-6).float()) @ bf(W1).t() + b1.double(), approximate="tanh")
+    xr = xr + bf(hid.float()) @ bf(W2).t() + b2.double()
+    yr = []
+    for i, N in enumerate(Ns):
+        ln = F.layer_norm(xr, (C,), lnw.double(), lnb.double(), 1e-5) if i == 0 else F.layer_norm(xr, (C,), None, None, 1e-6)
+        yr.append(bf(ln.float()) @ bf(Wn[i]).t() + bn[i].double())
+    xg, ys = G(x), [torch.full((M, N + 4), 3.0, device=DEV) for N in Ns]
+    def hw(w):
+        hi = split(hip, G(pad_w(w)), False)[0]
+        fr = torch.empty((w.shape[0] + 31) // 32 * 32 * w.shape[1], device=DEV, dtype=torch.int16)
+        hip.pack_frag_bf16(hi, hi.shape[1], w.shape[0], w.shape[1], fr)
+        return fr
+
+    who, wh1, wh2, whn = hw(Wo), hw(W1), hw(W2), [hw(w) for w in Wn]
+    nexts = []
+    for i, N in enumerate(Ns):
+        d = dict(w=whn[i], ldw=C, b=G(bn[i]), N=N, y=ys[i], ldy=N + 4, eps=1e-5 if i == 0 else 1e-6)
+        if i == 0:
+            d.update(lnw=G(lnw), lnb=G(lnb))
+        nexts.append(d)
+    hip.block_fused_bf16(xg, C, G(att) if with_att else None, Ko, Ko, who, Ko, G(bo), wh1, C, G(b1), wh2, H, G(b2), H, nexts, M, C)
+    torch.cuda.synchronize()
+    assert rel_err(xg, xr) < 3e-3
+    for i, N in enumerate(Ns):
+        assert rel_err(ys[i][:, :N], yr[i]) < 6e-3
+        assert bool((ys[i][:, N:] == 3.0).all())
+
+
 @pytest.mark.parametrize("M", [128, 1000, 13056])
 def test_mlp_fused_bf16(hip, M):
     g = torch.Generator().manual_seed(M)

@@ -67,6 +67,19 @@ def test_updateformer_sequence(model, golden):
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_updateformer_sequence_bf16(model, golden, fused):
+    """bf16 paths: fused block kernels (5 launches per layer) and the unfused sequence must agree with the fp32 golden
+    output to bf16 accuracy -- a buffer-reuse mistake in the sequencing would be off by O(1)."""
+    g = golden("updateformer_16x12")
+    model.precision = "bf16"
+    model.fuse_blocks = fused
+    out = model.update_former(T(g["x"]))
+    ref = g["out"]
+    err = np.abs(out.numpy() - ref).max() / np.abs(ref).max()
+    assert err < 3e-2, err
+
+
 @pytest.mark.parametrize("name", ["e2e_tiny", "e2e_two_windows", "e2e_short_clip"])
 def test_forward_sequence(model, golden, name):
     g = golden(name)

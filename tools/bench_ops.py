@@ -132,3 +132,21 @@ if "lngemm" in which:
         t_l = timeit(lambda: hip.layernorm(A, K, None, None, xn, K, M, K, 1e-6))
         t_f = timeit(lambda: hip.ln_gemm_bf16(A, K, None, None, 1e-6, hi, None, K, b, None, 0, Cm, N, M, N, K, 0))
         print(f"M={M} N={N} K={K}: gemm {t_g:.1f} us, layernorm {t_l:.1f} us, ln_gemm {t_f:.1f} us")
+
+if "block" in which:
+    C, H, Ko = 256, 1024, 288
+    def mk(n, k):
+        hi = split(torch.randn(n, k, device=dev) / math.sqrt(k), False)[0]
+        fr = torch.empty((n + 31) // 32 * 32 * k, device=dev, dtype=torch.int16)
+        hip.pack_frag_bf16(hi, k, n, k, fr)
+        return fr
+    who, wh1, wh2 = mk(C, Ko), mk(H, C), mk(C, H)
+    bo, b1, b2 = torch.randn(C, device=dev), torch.randn(H, device=dev), torch.randn(C, device=dev)
+    for M in (12288, 768):
+        x = torch.randn(M, C, device=dev)
+        att = torch.randn(M, Ko, device=dev)
+        for Ns in ([], [864], [576, 288]):
+            nexts = [dict(w=mk(N, C), ldw=256, b=torch.randn(N, device=dev), N=N, y=torch.empty(M, N, device=dev), ldy=N, eps=1e-6) for N in Ns]
+            t_f = timeit(lambda: hip.block_fused_bf16(x, C, att, Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, H, b2, H, nexts, M, C))
+            t_n = timeit(lambda: hip.block_fused_bf16(x, C, None, Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, H, b2, H, [], M, C))
+            print(f"block_fused M={M} nexts={Ns}: {t_f:.1f} us   (MLP only: {t_n:.1f} us)")
