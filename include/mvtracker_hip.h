@@ -250,6 +250,11 @@ int mvt_layernorm(const float* x, int ldx, const float* w, const float* b, float
 int mvt_attention(const float* q, int ldq, long long q_gs, long long q_is, const float* k, const float* v,
                   int ldkv, long long k_gs, long long k_is, float* o, int ldo, int groups, int nq, int nk,
                   int heads, int dh, void* stream);
+/* Same contract on the bf16 matrix cores (flash-style, scores never leave registers; dh == 48): q/k/v are rounded to
+ * bf16, accumulation and softmax in fp32. */
+int mvt_attention_bf16(const float* q, int ldq, long long q_gs, long long q_is, const float* k, const float* v,
+                       int ldkv, long long k_gs, long long k_is, float* o, int ldo, int groups, int nq, int nk,
+                       int heads, int dh, void* stream);
 /* x[(n*S+s)*ld + 0:C] = v[n][0:C] for all s  (virtual-token broadcast, blocks.py:458-459). */
 int mvt_broadcast_rows(const float* v, float* x, int ld, int n, int S, int C, void* stream);
 

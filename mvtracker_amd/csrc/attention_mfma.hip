@@ -1,0 +1,268 @@
+// Flash-style attention on the bf16 matrix cores for the updater's space attention (virtual<-point: 64 queries x N
+// keys; point<-virtual: N queries x 64 keys; virtual self: 64 x 64; cotracker2/blocks.py:258-271), head width 48.
+//
+// A wave owns 64 queries (two 32-wide MFMA blocks) of one (group, head) and walks the keys 32 at a time:
+//     S^T (key x query)  = K_blk (32 x 48) . Q^T        A = K rows straight from global (fp32 -> bf16), B = Q rows
+//     online softmax over the key index = over the 16 accumulator registers (+ the partner half-wave, one shuffle)
+//     O^T (d x query)   += V^T (d x key) . P^T          B = P^T taken from the accumulator (registers 8s..8s+7 are the
+//                                                       B fragment of k-step s), A = V^T from a small transposed LDS
+//                                                       image read in the accumulator's key order
+// so scores and probabilities never leave registers and the output lands with the query on the lane (row stores).
+// KS > 1 splits the keys of one query chunk over KS waves; their (m, l, O^T) states are merged through LDS.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DH = 48;
+constexpr int LDV = 40;  // bf16 row stride of the V^T image: 32 keys + 8 pad (80 B)
+
+__device__ __forceinline__ bf16x8 cvt8(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  const bf16x4 x = __builtin_convertvector(a, bf16x4), y = __builtin_convertvector(b, bf16x4);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = x[e];
+    o[4 + e] = y[e];
+  }
+  return o;
+}
+
+template <int KS>
+__global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel(
+    const float* __restrict__ q, int ldq, long long q_gs, long long q_is, const float* __restrict__ k, const float* __restrict__ v,
+    int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads) {
+  constexpr int NW = KS == 1 ? 4 : KS;
+  constexpr int VT = 64 * LDV;                              // bf16 elements of one wave's V^T image (64 d rows)
+  constexpr int MERGE = KS > 1 ? (KS - 1) * 64 * 68 : 0;    // floats: per lane m[2], l[2], 64 accumulators
+  __shared__ __attribute__((aligned(16))) unsigned short vts[NW * VT];
+  __shared__ float red[MERGE > 0 ? MERGE : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  unsigned short* vt = vts + wave * VT;
+
+  const int chunks = (nq + 63) / 64;
+  const long long nchunk = (long long)groups * heads * chunks;
+  const long long chunk_id = KS == 1 ? (long long)blockIdx.x * 4 + wave : (long long)blockIdx.x;
+  const bool chunk_ok = chunk_id < nchunk;
+  const long long cid = chunk_ok ? chunk_id : 0;
+  const int qc = (int)(cid % chunks);
+  const int hd = (int)((cid / chunks) % heads);
+  const long long g = cid / ((long long)chunks * heads);
+
+  // Q^T fragments (B operand): lane (r, h) of block mb holds Q[query qc*64 + mb*32 + r][ks*16 + 8h ..], pre-scaled
+  const float scale = 1.0f / sqrtf((float)DH);
+  bf16x8 qf[2][3];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int qi = qc * 64 + mb * 32 + r;
+    const float* qp = q + (g * q_gs + (long long)(qi < nq ? qi : nq - 1) * q_is) * ldq + hd * DH;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 8 * h), b = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 8 * h + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] *= scale;
+        b[e] *= scale;
+      }
+      const bf16x4 x = __builtin_convertvector(a, bf16x4), y = __builtin_convertvector(b, bf16x4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qf[mb][ks][e] = x[e];
+        qf[mb][ks][4 + e] = y[e];
+      }
+    }
+  }
+  // rows 48..63 of the V^T image stay zero (d padding of the second 32-row block)
+  for (int i = lane; i < 16 * LDV; i += 64) vt[48 * LDV + i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+  f32x16 oacc[2][2];  // [mb][db]: O^T rows d = db*32 + .., column = query
+  float m[2], l[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    m[mb] = -INFINITY;
+    l[mb] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[mb][db][e] = 0.f;
+  }
+
+  const int nkb = (nk + 31) / 32;                       // key blocks
+  const int per = (nkb + KS - 1) / KS;
+  const int kb0 = KS == 1 ? 0 : wave * per;
+  const int kb1 = KS == 1 ? nkb : (kb0 + per < nkb ? kb0 + per : nkb);
+  const float* kbase = k + (g * k_gs) * ldkv + hd * DH;
+  const float* vbase = v + (g * k_gs) * ldkv + hd * DH;
+  const long long kstep = k_is * ldkv;
+
+#pragma unroll 1
+  for (int kb = kb0; kb < kb1; ++kb) {
+    // ---- K block: A fragments (key row r of this block, k = d)
+    const int key = kb * 32 + r;
+    const float* kp = kbase + (long long)(key < nk ? key : nk - 1) * kstep;
+    bf16x8 kf[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) kf[ks] = cvt8(kp + ks * 16 + 8 * h);
+    // ---- V block -> transposed LDS image vt[d][key]: lane handles key (lane & 31), d range 24 * (lane >> 5) .. +23
+    {
+      const float* vp = vbase + (long long)(key < nk ? key : nk - 1) * kstep + 24 * h;
+      // (the image is written as 16-bit elements and read back as 32-bit vectors: a wavefront-scope fence keeps the
+      //  compiler's type-based alias analysis from reordering the two)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(vp + 4 * i);
+        if (key >= nk) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (16-bit element extraction from the packed bf16 vector is done on the 32-bit words: hipcc 7.2 emits
+        //  ds_write_b16 of the same low half for every element of `b[e]` otherwise)
+        const u32x2 w = __builtin_bit_cast(u32x2, __builtin_convertvector(a, bf16x4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vt[(24 * h + 4 * i + e) * LDV + r] = (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xFFFFu));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    // ---- S^T = K . Q^T, online softmax, O^T += V^T . P^T
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[mb][ks], s, 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kk = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;  // key index of this register
+        if (kk >= nk) s[e] = -INFINITY;
+        mx = fmaxf(mx, s[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[mb], mx);
+      const float corr = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s[e] = __expf(s[e] - mn);
+        ps += s[e];
+      }
+      l[mb] = l[mb] * corr + ps;  // per-lane partial (this half-wave's key rows); halves are added at the end
+      m[mb] = mn;
+      if (__ballot(corr != 1.0f)) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[mb][db][e] *= corr;
+      }
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {  // two k-steps of 16 keys: P^T fragment = registers 8sk .. 8sk+7
+        f32x4 lo4, hi4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo4[e] = s[8 * sk + e];
+          hi4[e] = s[8 * sk + 4 + e];
+        }
+        const bf16x4 bl = __builtin_convertvector(lo4, bf16x4), bh = __builtin_convertvector(hi4, bf16x4);
+        bf16x8 pb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pb[e] = bl[e];
+          pb[4 + e] = bh[e];
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          // V^T fragment in the accumulator's key order: keys 16sk + 4h + (0..3) and + 8, row d = db*32 + r
+          const unsigned short* vr = &vt[(db * 32 + r) * LDV + 16 * sk + 4 * h];
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(vr), a1 = *reinterpret_cast<const u32x2*>(vr + 8);
+          const bf16x8 va = __builtin_bit_cast(bf16x8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
+          oacc[mb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, oacc[mb][db], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (KS > 1) {
+    if (wave > 0) {
+      float* rr = red + ((wave - 1) * 64 + lane) * 68;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        rr[mb] = m[mb];
+        rr[2 + mb] = l[mb];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rr[4 + (mb * 2 + db) * 16 + e] = oacc[mb][db][e];
+      }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll 1
+    for (int w = 0; w < KS - 1; ++w) {
+      const float* rr = red + (w * 64 + lane) * 68;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float mw = rr[mb];
+        // both half-waves of a query share m (it is exchanged above), so the merge is lane-local
+        const float mn = fmaxf(m[mb], mw);
+        const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
+        const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
+        l[mb] = l[mb] * ca + rr[2 + mb] * cb;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = oacc[mb][db][e] * ca + rr[4 + (mb * 2 + db) * 16 + e] * cb;
+        m[mb] = mn;
+      }
+    }
+  }
+  if (!chunk_ok) return;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float lt = l[mb] + __shfl_xor(l[mb], 32, 64);
+    const float inv = 1.0f / lt;
+    const int qi = qc * 64 + mb * 32 + r;
+    if (qi >= nq) continue;
+    float* op = o + (g * q_gs + (long long)qi * q_is) * ldo + hd * DH;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = db * 32 + 8 * gq + 4 * h;
+        if (d < DH) {
+          f32x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = oacc[mb][db][4 * gq + e] * inv;
+          *reinterpret_cast<f32x4*>(op + d) = t;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mvt_attention_bf16(const float* q, int ldq, long long q_gs, long long q_is, const float* k, const float* v,
+                                  int ldkv, long long k_gs, long long k_is, float* o, int ldo, int groups, int nq, int nk,
+                                  int heads, int dh, void* stream) {
+  MVT_REQUIRE(q && k && v && o && groups > 0 && nq > 0 && nk > 0 && heads > 0 && dh == DH);
+  MVT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= heads * dh && ldkv >= heads * dh && ldo >= heads * dh);
+  MVT_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 16 == 0));
+  const long long nchunk = (long long)groups * heads * ((nq + 63) / 64);
+#define LAUNCH(KS, BLOCKS, THREADS)                                                                                        \
+  hipLaunchKernelGGL((attention_mfma_kernel<KS>), dim3((unsigned)(BLOCKS)), dim3(THREADS), 0, mvt_stream(stream), q, ldq, q_gs, \
+                     q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads)
+  if (nk >= 512 && nchunk < 1024) {
+    LAUNCH(4, nchunk, 256);
+  } else {
+    LAUNCH(1, mvt_cdiv(nchunk, 4), 256);
+  }
+#undef LAUNCH
+  return mvt_launch_status();
+}

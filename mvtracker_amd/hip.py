@@ -56,6 +56,7 @@ SIGNATURES = {
     "mvt_rowdot": [P, I, P, P, P, LL, I, P],
     "mvt_layernorm": [P, I, P, P, P, I, LL, I, F, P],
     "mvt_attention": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, P],
+    "mvt_attention_bf16": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, P],
     "mvt_broadcast_rows": [P, P, I, I, I, I, P],
 }
 _RET = {"mvt_build_arch": C.c_char_p}
@@ -249,6 +250,11 @@ def layernorm(x, ldx, w, b, y, ldy, rows, Cc, eps):
 
 def attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
     _call("mvt_attention", _ptr(q), ldq, q_gs, q_is, _ptr(k), _ptr(v), ldkv, k_gs, k_is, _ptr(o), ldo, groups, nq, nk, heads,
+          dh, _stream())
+
+
+def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
+    _call("mvt_attention_bf16", _ptr(q), ldq, q_gs, q_is, _ptr(k), _ptr(v), ldkv, k_gs, k_is, _ptr(o), ldo, groups, nq, nk, heads,
           dh, _stream())
 
 

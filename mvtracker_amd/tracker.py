@@ -106,6 +106,7 @@ class MVTracker(nn.Module):
         self.precision = os.environ.get("MVT_PRECISION", "fp32")
         self.fuse_mlp = True
         self.fuse_blocks = True
+        self.mfma_attention = True
         self.fuse_ln = False
         d = self.updateformer_input_dim
         self._time_embed_host = self._make_time_embed(self.S, d)
@@ -475,6 +476,7 @@ class MVTracker(nn.Module):
         qp = torch.empty(Mp, inner, device=dev)       # point <- virtual queries (computed right after the time block)
         att = torch.empty(M, inner, device=dev)
         u = "updateformer."
+        space_attn = hip.attention_bf16 if (self.mfma_attention and dh == 48) else hip.attention
         self._lin(pk, u + "input_transform", x, ldx, Mp, tok, h)
         hip.broadcast_rows(pk["virtual"], tok[Mp:], h, nv, S, h)
         pt, vt = tok[:Mp], tok[Mp:]
@@ -491,18 +493,18 @@ class MVTracker(nn.Module):
                                self._next(pk, p2v + ".cross_attn.to_q", qp, inner)])
             self._fused_block(pk, tb, "attn", vt, Mv, att[Mp:], [self._next(pk, v2p + ".cross_attn.to_q", qkv[Mp:], 3 * inner)])
             # virtual <- point
-            hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, n, H,
-                          dh)
+            space_attn(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, n, H,
+                       dh)
             self._fused_block(pk, v2p, "cross_attn", vt, Mv, att[Mp:], [self._next(pk, vs + ".attn.qkv", qkv[Mp:], 3 * inner)])
             # virtual self attention
-            hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, nv, H,
-                          dh)
+            space_attn(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, nv, H,
+                       dh)
             nx = [self._next(pk, p2v + ".cross_attn.to_kv", qkv[Mp:, inner:], 3 * inner, pk[p2v + ".norm_context"], 1e-5)]
             # (the next time block's q|k|v of the virtual rows would overwrite the k|v just produced: it is projected
             #  after the point <- virtual attention has consumed them, see below)
             self._fused_block(pk, vs, "attn", vt, Mv, att[Mp:], nx)
             # point <- virtual
-            hip.attention(qp, inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[:Mp], inner, S, n, nv, H, dh)
+            space_attn(qp, inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[:Mp], inner, S, n, nv, H, dh)
             self._fused_block(pk, p2v, "cross_attn", pt, Mp, att[:Mp], [] if last else [self._next(pk, nxt_qkv, qkv[:Mp], 3 * inner)])
             if not last:
                 self._ln_lin(pk, nxt_qkv, vt, Mv, qkv[Mp:], 3 * inner, xn[Mp:])

@@ -316,6 +316,10 @@ def attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk
     torch.as_strided(o, (groups, nq, heads, dh), (q_gs * ldo, q_is * ldo, dh, 1)).copy_(y)
 
 
+def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
+    attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh)
+
+
 def broadcast_rows(v, x, ld, n, S, Cc):
     torch.as_strided(x, (n, S, Cc), (S * ld, ld, 1)).copy_(v.reshape(n, 1, Cc).expand(n, S, Cc))
 
@@ -335,5 +339,5 @@ def install(monkeypatch):
     me = sys.modules[__name__]
     for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_bf16 ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
                  "depth_subsample avgpool2 unproject knn_scan knn_merge corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
-                 "rowdot layernorm attention broadcast_rows window_corr require_device").split():
+                 "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

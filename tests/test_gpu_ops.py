@@ -518,6 +518,35 @@ def test_attention(hip, mode, n):
     assert (got.double() - ref).abs().max() < 2e-6
 
 
+@pytest.mark.parametrize("n", [50, 200, 1024])
+@pytest.mark.parametrize("mode", ["v2p", "vself", "p2v"])
+def test_attention_bf16(hip, mode, n):
+    g = torch.Generator().manual_seed(4)
+    nv, S, H, dh = 64, 12, 6, 48
+    inner = H * dh
+    M = (n + nv) * S
+    Mp = n * S
+    qkv = torch.randn(M, 3 * inner, generator=g)
+    out = torch.zeros(M, inner, device=DEV)
+    qg = G(qkv)
+    tok = qkv.reshape(n + nv, S, 3, H, dh)
+    pq, vq = tok[:n], tok[n:]
+    if mode == "v2p":
+        hip.attention_bf16(qg[Mp:], 3 * inner, 1, S, qg[:Mp, inner:], qg[:Mp, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, n, H, dh)
+        q, k, v, sl = vq[:, :, 0], pq[:, :, 1], pq[:, :, 2], slice(Mp, M)
+    elif mode == "vself":
+        hip.attention_bf16(qg[Mp:], 3 * inner, 1, S, qg[Mp:, inner:], qg[Mp:, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, nv, H, dh)
+        q, k, v, sl = vq[:, :, 0], vq[:, :, 1], vq[:, :, 2], slice(Mp, M)
+    else:
+        hip.attention_bf16(qg[:Mp], 3 * inner, 1, S, qg[Mp:, inner:], qg[Mp:, 2 * inner:], 3 * inner, 1, S, out[:Mp], inner, S, n, nv, H, dh)
+        q, k, v, sl = pq[:, :, 0], vq[:, :, 1], vq[:, :, 2], slice(0, Mp)
+    q, k, v = (t.permute(1, 2, 0, 3).double() for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(q, k, v).permute(2, 0, 1, 3).reshape(-1, inner)
+    torch.cuda.synchronize()
+    got = out[sl].cpu().double()
+    assert (got - ref).abs().max() < 3e-2 and (got - ref).abs().mean() < 3e-3  # bf16 operands / probabilities
+
+
 def test_delta_split_rowdot_broadcast(hip):
     g = torch.Generator().manual_seed(9)
     rows, C = 500, 128
