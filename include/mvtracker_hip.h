@@ -84,9 +84,17 @@ int mvt_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, lon
 int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const unsigned short* w_lo, int ldw,
                   const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int act,
                   void* stream);
+/* InstanceNorm fusion of the bf16 convolutions (saves the separate statistics pass and the normalise pass between
+ * the two convs of a ResidualBlock, blocks.py:119-122):
+ *   in_stats    [n][Cin][2] (mean, rstd) or NULL: the input is read as relu((x - mean) * rstd) (3x3 stride-1 pad-1 only);
+ *   out_partial [n][slots][Cout][2] or NULL: per-channel (sum, sum of squares) of the outputs of every 32-pixel block,
+ *               slots = mvt_conv2d_stat_slots(...) (0 = not available for this shape); one writer per slot, reduced in a
+ *               fixed order by mvt_instnorm_finish_slots -> deterministic. */
+int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad);
 int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
                     float* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
-                    int act, void* stream);
+                    int act, const float* in_stats, float* out_partial, void* stream);
+int mvt_instnorm_finish_slots(const float* partial, int slots, float* mean_rstd, int n, long long HW, int C, void* stream);
 
 /* mvt_gemm_bf16 with LayerNorm (biased variance, eps, optional affine ln_w / ln_b of length K) applied to every A
  * row on the fly: C = R + act(LayerNorm(A) . W^T + bias).  K % 4 == 0, K <= 1024.  Replaces the norm1 / norm_context

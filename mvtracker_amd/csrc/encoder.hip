@@ -103,6 +103,37 @@ __global__ void instnorm_finish_kernel(const double* __restrict__ partial, float
   mean_rstd[i * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
 }
 
+// block (channel group of 16, image): 64 slot lanes x 16 channels accumulate in fp64, fixed-order LDS reduction
+__global__ __launch_bounds__(1024) void instnorm_finish_slots_kernel(const float* __restrict__ partial, int slots,
+                                                                     float* __restrict__ mean_rstd, long long HW, int C) {
+  __shared__ double red[1024 * 2];
+  const int t = threadIdx.x, c = blockIdx.x * 16 + (t & 15), l = t >> 4;
+  const long long img = blockIdx.y;
+  double s = 0, ss = 0;
+  if (c < C) {
+    for (int sl = l; sl < slots; sl += 64) {
+      const float2 v = *reinterpret_cast<const float2*>(partial + ((img * slots + sl) * C + c) * 2);
+      s += (double)v.x;
+      ss += (double)v.y;
+    }
+  }
+  red[t * 2] = s;
+  red[t * 2 + 1] = ss;
+  __syncthreads();
+  if (t < 16 && c < C) {
+    s = 0, ss = 0;
+    for (int k = 0; k < 64; ++k) {
+      s += red[(k * 16 + t) * 2];
+      ss += red[(k * 16 + t) * 2 + 1];
+    }
+    double mean = s / (double)HW;
+    double var = ss / (double)HW - mean * mean;
+    if (var < 0) var = 0;
+    mean_rstd[(img * C + c) * 2] = (float)mean;
+    mean_rstd[(img * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+}
+
 __global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ st, const float* __restrict__ skip,
                                       const float* __restrict__ skst, float* __restrict__ y, long long HW, int C, long long total4) {
   const int cq = C / 4;
@@ -187,6 +218,13 @@ extern "C" int mvt_instnorm_stats(const float* x, int ldx, double* partial, floa
   long long total = (long long)n * C;
   hipLaunchKernelGGL(instnorm_finish_kernel, dim3((unsigned)mvt_cdiv(total, 256)), dim3(256), 0, mvt_stream(stream), partial,
                      mean_rstd, HW, C, total);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_instnorm_finish_slots(const float* partial, int slots, float* mean_rstd, int n, long long HW, int C, void* stream) {
+  MVT_REQUIRE(partial && mean_rstd && slots > 0 && n > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(instnorm_finish_slots_kernel, dim3((unsigned)mvt_cdiv(C, 16), (unsigned)n), dim3(1024), 0, mvt_stream(stream),
+                     partial, slots, mean_rstd, HW, C);
   return mvt_launch_status();
 }
 

@@ -32,6 +32,11 @@ struct GemmArgs {
   const unsigned short* Whi;  // bf16 kernels: weights pre-split into bf16 hi (+ lo for the split-precision mode)
   const unsigned short* Wlo;
   // optional LayerNorm fused into the A loader of the dense bf16 kernels (K <= 1024): a = (a - mean) * rstd [* w + b]
+  // InstanceNorm fusion (bf16 conv kernels): in_stats [n][Cin][2] (mean, rstd) -> the loader applies relu((x-mean)*rstd)
+  // (3x3 halo kernel only); out_part [n][slots][N][2] receives per-32-row-block sums / sums of squares of the outputs
+  const float* in_stats;
+  float* out_part;
+  int slots;
   int ln;
   float ln_eps;
   const float* ln_w;
@@ -440,17 +445,32 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + r;
-    if (n >= p.N) continue;
-    const float bv = p.bias ? p.bias[n] : 0.f;
+    const bool nok = n < p.N;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         long long m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m < p.M) {
+        if (nok && m < p.M) {
           float v = mvt_act(acc[i][j][e] + bv, p.act);
           if (p.R) v += p.R[m * p.ldr + n];
           p.C[m * p.ldc + n] = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+      }
+      if (p.out_part) {  // conv mode, Ho*Wo % 32 == 0: this 32-row block lies inside one image
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const long long mrow = m0 + (wm * TM + i) * 32;
+        const long long hw = (long long)p.Ho * p.Wo;
+        if (h == 0 && nok && mrow < p.M) {
+          const long long im = mrow / hw, slot = (mrow - im * hw) / 32;
+          float* pp = p.out_part + ((im * p.slots + slot) * p.N + n) * 2;
+          pp[0] = s1;
+          pp[1] = s2;
         }
       }
     }
@@ -529,10 +549,23 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16(GemmArgs p) {
       if (pok[i]) rp[i] = *reinterpret_cast<const f32x4*>(in + poff[i] + c0);
     }
   };
+  f32x4 st_m = (f32x4){0.f, 0.f, 0.f, 0.f}, st_r = (f32x4){1.f, 1.f, 1.f, 1.f};  // stats of this thread's channel quad
+  auto load_stats = [&](int c0) {
+    if (p.in_stats) {
+      const float* sp = p.in_stats + (img * p.Cin + c0 + (t & 7) * 4) * 2;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+      st_m = (f32x4){a[0], a[2], b[0], b[2]};
+      st_r = (f32x4){a[1], a[3], b[1], b[3]};
+    }
+  };
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       if (plds[i] >= 0) {
+        if (p.in_stats && pok[i]) {  // zero padding applies AFTER the normalisation: out-of-image taps stay 0
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rp[i][e] = fmaxf((rp[i][e] - st_m[e]) * st_r[e], 0.f);
+        }
         uint2 hi, lo;
         split4(rp[i], hi, lo);
         *reinterpret_cast<uint2*>(&Ph[plds[i]]) = hi;
@@ -582,10 +615,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16(GemmArgs p) {
 
   const int nchunk = p.Cin / CK;
   load_patch(0);
+  load_stats(0);
   load_w(0, 0);
   for (int c = 0; c < nchunk; ++c) {
     store_patch();
-    if (c + 1 < nchunk) load_patch((c + 1) * CK);
+    if (c + 1 < nchunk) {
+      load_patch((c + 1) * CK);
+      load_stats((c + 1) * CK);
+    }
 #pragma unroll 1
     for (int kh = 0; kh < 3; ++kh) {
       store_w();
@@ -629,15 +666,31 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + r;
-    if (n >= p.N) continue;
-    const float bv = p.bias ? p.bias[n] : 0.f;
+    const bool nok = n < p.N;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int y = y0 + m / HW_, x = x0 + m % HW_;
-        if (y < p.Ho && x < p.Wo) outb[((long long)y * p.Wo + x) * p.ldc + n] = mvt_act(acc[i][j][e] + bv, p.act);
+        if (nok && y < p.Ho && x < p.Wo) {
+          const float v = mvt_act(acc[i][j][e] + bv, p.act);
+          outb[((long long)y * p.Wo + x) * p.ldc + n] = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+      }
+      if (p.out_part) {  // per-channel sums of this 32-pixel block (deterministic: one writer per slot)
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const long long slot = ((long long)ty * tiles_x + tx) * 4 + wm * TM + i;
+        if (h == 0 && nok) {
+          float* pp = p.out_part + ((img * p.slots + slot) * p.N + n) * 2;
+          pp[0] = s1;
+          pp[1] = s2;
+        }
       }
     }
   }
@@ -771,9 +824,16 @@ extern "C" int mvt_gemm_bf16(const float* A, int lda, const unsigned short* Whi,
   return Wlo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));
 }
 
+extern "C" int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad) {
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0) return (int)(mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4);
+  return ((long long)Ho * Wo) % 256 == 0 ? Ho * Wo / 32 : 0;  // im2col tiles are <= 256 rows: they must not straddle images
+}
+
 extern "C" int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
                                float* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
-                               int act, void* stream) {
+                               int act, const float* in_stats, float* out_partial, void* stream) {
   MVT_REQUIRE(in && wt_hi && out && n > 0 && H > 0 && W > 0 && Cout > 0);
   MVT_REQUIRE(KH >= 1 && KH <= 7 && KW >= 1 && KW <= 7 && stride >= 1 && stride <= 2 && pad >= 0 && pad <= 3);
   MVT_REQUIRE(H < 16384 && W < 16384 && ldo >= Cout && act >= 0 && act <= 3);
@@ -796,6 +856,12 @@ extern "C" int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, con
   a.nk = (a.K + BKB - 1) / BKB;
   a.ldw = a.nk * BKB;  // weights are [Cout][round_up(K, 64)], zero padded
   a.lda = 0;
+  const bool halo = KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0;
+  MVT_REQUIRE(!in_stats || (halo && ((uintptr_t)in_stats % 16 == 0)));  // normalise-on-load exists in the halo kernel only
+  a.in_stats = in_stats;
+  a.out_part = out_partial;
+  a.slots = mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad);
+  MVT_REQUIRE(!out_partial || a.slots > 0);
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0 && (long long)n * mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4 < (1LL << 31))
     return wt_lo ? launch_conv3x3_halo<true>(a, n, mvt_stream(stream)) : launch_conv3x3_halo<false>(a, n, mvt_stream(stream));
   return wt_lo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));

@@ -31,7 +31,9 @@ SIGNATURES = {
     "mvt_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "mvt_split_bf16": [P, P, P, LL, P],
     "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, P],
-    "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "mvt_conv2d_stat_slots": [I, I, I, I, I, I, I],
+    "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P],
+    "mvt_instnorm_finish_slots": [P, I, P, I, LL, I, P],
     "mvt_ln_gemm_bf16": [P, I, P, P, F, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_pack_frag_bf16": [P, I, I, I, P, P],
     "mvt_block_fused_bf16": [P, I, P, I, I, P, I, P, P, I, P, P, I, P, I, P, I, LL, I, P],
@@ -129,9 +131,18 @@ def gemm_bf16(A, lda, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NON
           _stream())
 
 
-def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE):
+def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad) -> int:
+    return _lib.mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad)
+
+
+def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE, in_stats=None,
+                out_partial=None):
     _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
-          ldo, act, _stream())
+          ldo, act, _ptr(in_stats), _ptr(out_partial), _stream())
+
+
+def instnorm_finish_slots(partial, slots, mean_rstd, n, HW, Cc):
+    _call("mvt_instnorm_finish_slots", _ptr(partial), slots, _ptr(mean_rstd), n, HW, Cc, _stream())
 
 
 def ln_gemm_bf16(A, lda, ln_w, ln_b, eps, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NONE):

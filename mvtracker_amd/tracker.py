@@ -107,6 +107,7 @@ class MVTracker(nn.Module):
         self.fuse_mlp = True
         self.fuse_blocks = True
         self.mfma_attention = True
+        self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
         d = self.updateformer_input_dim
         self._time_embed_host = self._make_time_embed(self.S, d)
@@ -265,45 +266,59 @@ class MVTracker(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ encoder (reference spatracker/blocks.py:214-284)
-    def _conv(self, pk, name, x, n, H, W, cin, cout, k, stride, pad, out=None, ldo=None):
+    def _conv(self, pk, name, x, n, H, W, cin, cout, k, stride, pad, out=None, ldo=None, in_stats=None, stats=False):
+        """Convolution; ``stats=True`` also returns the InstanceNorm (mean, rstd) of the output (taken from the conv epilogue
+        on the bf16 kernels), ``in_stats`` makes the kernel read its input as relu(IN(x)) (bf16 3x3 stride-1 only)."""
         wt, b = pk[name]
         Ho = (H + 2 * pad - k) // stride + 1
         Wo = (W + 2 * pad - k) // stride + 1
         if out is None:
             out = torch.empty(n, Ho, Wo, cout, device=x.device)
             ldo = cout
+        st = None
         if isinstance(wt, tuple):
-            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo)
+            slots = hip.conv2d_stat_slots(H, W, cin, k, k, stride, pad) if (stats and self.fuse_norm) else 0
+            part = torch.empty(n * slots * cout * 2, device=x.device) if slots else None
+            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo, in_stats=in_stats, out_partial=part)
+            if slots:
+                st = torch.empty(n, cout, 2, device=x.device)
+                hip.instnorm_finish_slots(part, slots, st, n, Ho * Wo, cout)
         else:
+            assert in_stats is None
             hip.conv2d(x, wt, b, out, n, H, W, cin, cout, k, k, stride, pad, ldo)
-        return out, Ho, Wo
+        if stats and st is None:
+            st = self._inorm(out, n, Ho * Wo, cout, apply=False)
+        return (out, Ho, Wo, st) if stats else (out, Ho, Wo)
 
-    def _inorm(self, x, n, HW, C, skip=None, skip_stats=None, apply=True):
-        partial = torch.empty(n * hip.IN_SLABS * C * 2, device=x.device, dtype=torch.float64)
-        st = torch.empty(n, C, 2, device=x.device)
-        hip.instnorm_stats(x, C, partial, st, n, HW, C)
+    def _inorm(self, x, n, HW, C, skip=None, skip_stats=None, apply=True, st=None):
+        if st is None:
+            partial = torch.empty(n * hip.IN_SLABS * C * 2, device=x.device, dtype=torch.float64)
+            st = torch.empty(n, C, 2, device=x.device)
+            hip.instnorm_stats(x, C, partial, st, n, HW, C)
         if apply:
             hip.instnorm_apply(x, st, skip, skip_stats, x, n, HW, C)
         return st
 
     def _res_block(self, pk, p, x, n, H, W, cin, cout, stride):
-        y, Ho, Wo = self._conv(pk, p + ".conv1", x, n, H, W, cin, cout, 3, stride, 1)
-        self._inorm(y, n, Ho * Wo, cout)
-        y2, _, _ = self._conv(pk, p + ".conv2", y, n, Ho, Wo, cout, cout, 3, 1, 1)
+        fuse_in = self.fuse_norm and isinstance(pk[p + ".conv2"][0], tuple) and cout % 32 == 0
+        y, Ho, Wo, st1 = self._conv(pk, p + ".conv1", x, n, H, W, cin, cout, 3, stride, 1, stats=True)
+        if not fuse_in:  # otherwise conv2 normalises while it loads its patch
+            self._inorm(y, n, Ho * Wo, cout, st=st1)
+        y2, _, _, st2 = self._conv(pk, p + ".conv2", y, n, Ho, Wo, cout, cout, 3, 1, 1, in_stats=st1 if fuse_in else None,
+                                   stats=True)
         if (p + ".downsample.0") in pk:
-            d, _, _ = self._conv(pk, p + ".downsample.0", x, n, H, W, cin, cout, 1, stride, 0)
-            dst = self._inorm(d, n, Ho * Wo, cout, apply=False)
-            self._inorm(y2, n, Ho * Wo, cout, skip=d, skip_stats=dst)
+            d, _, _, dst = self._conv(pk, p + ".downsample.0", x, n, H, W, cin, cout, 1, stride, 0, stats=True)
+            self._inorm(y2, n, Ho * Wo, cout, skip=d, skip_stats=dst, st=st2)
         else:
-            self._inorm(y2, n, Ho * Wo, cout, skip=x)
+            self._inorm(y2, n, Ho * Wo, cout, skip=x, st=st2)
         return y2, Ho, Wo
 
     def _encode(self, pk, x4, n, H, W, out_rows):
         """x4 (n,H,W,4) normalised RGB -> writes (n, H/4, W/4, C) into ``out_rows``."""
         C = self.latent_dim
         hs, ws = H // self.stride, W // self.stride
-        x, h, w = self._conv(pk, "fnet.conv1", x4, n, H, W, 4, 64, 7, 2, 3)
-        self._inorm(x, n, h * w, 64)
+        x, h, w, st = self._conv(pk, "fnet.conv1", x4, n, H, W, 4, 64, 7, 2, 3, stats=True)
+        self._inorm(x, n, h * w, 64, st=st)
         cat = torch.empty(n, hs, ws, 416, device=x4.device)
         cin, off = 64, 0
         for li, (cout, stride) in enumerate(((64, 1), (96, 2), (128, 2), (128, 2)), start=1):
@@ -311,8 +326,8 @@ class MVTracker(nn.Module):
             x, h, w = self._res_block(pk, f"fnet.layer{li}.1", x, n, h, w, cout, cout, 1)
             hip.resize_bilinear_ac(x, cat, n, h, w, cout, hs, ws, 416, off)
             cin, off = cout, off + cout
-        y, _, _ = self._conv(pk, "fnet.conv2", cat, n, hs, ws, 416, 2 * C, 3, 1, 1)
-        self._inorm(y, n, hs * ws, 2 * C)
+        y, _, _, st = self._conv(pk, "fnet.conv2", cat, n, hs, ws, 416, 2 * C, 3, 1, 1, stats=True)
+        self._inorm(y, n, hs * ws, 2 * C, st=st)
         self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C)
 
     def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16):

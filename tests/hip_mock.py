@@ -106,12 +106,40 @@ def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
     xv += _bf(hdn) @ W2.t() + b2[:Cc]
 
 
-def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0):
+def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad):
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    if KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cin % 32 == 0:
+        return ((Ho + 7) // 8) * ((Wo + 15) // 16) * 4
+    return Ho * Wo // 32 if (Ho * Wo) % 256 == 0 else 0
+
+
+def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0, in_stats=None, out_partial=None):
     K = KH * 32 if Cin == 4 else KH * KW * Cin
     ld = (K + 63) // 64 * 64
     w = _w_from_bf16(wt_hi, wt_lo, Cout, ld).contiguous()
-    xin = x if wt_lo is not None else _bf(x)
+    xin = x
+    if in_stats is not None:
+        st = in_stats.reshape(n, 1, Cin, 2)
+        xin = F.relu((torch.as_strided(x, (n, H * W, Cin), (H * W * Cin, Cin, 1)) - st[..., 0]) * st[..., 1]).contiguous()
+    xin = xin if wt_lo is not None else _bf(xin)
     conv2d(xin, w, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act)
+    if out_partial is not None:  # the mock puts the whole image sum into slot 0
+        slots = conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad)
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        y = torch.as_strided(out, (n, Ho * Wo, Cout), (Ho * Wo * ldo, ldo, 1))
+        pp = out_partial.reshape(-1)[:n * slots * Cout * 2].reshape(n, slots, Cout, 2)
+        pp.zero_()
+        pp[:, 0, :, 0] = y.sum(1)
+        pp[:, 0, :, 1] = (y * y).sum(1)
+
+
+def instnorm_finish_slots(partial, slots, mean_rstd, n, HW, Cc):
+    pp = partial.reshape(-1)[:n * slots * Cc * 2].reshape(n, slots, Cc, 2).double().sum(1)
+    mean = pp[..., 0] / HW
+    var = (pp[..., 1] / HW - mean * mean).clamp_min(0)
+    st = mean_rstd.reshape(n, Cc, 2)
+    st[..., 0] = mean.float()
+    st[..., 1] = (1.0 / torch.sqrt(var + 1e-5)).float()
 
 
 def conv2d(x, wt, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0):
@@ -337,7 +365,7 @@ def install(monkeypatch):
     import sys
     from mvtracker_amd import hip
     me = sys.modules[__name__]
-    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_bf16 ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
+    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
                  "depth_subsample avgpool2 unproject knn_scan knn_merge corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

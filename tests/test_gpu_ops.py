@@ -119,6 +119,54 @@ def test_conv2d(hip, cfg, prec):
     assert rel_err(out.permute(0, 3, 1, 2), ref) < PREC_TOL[prec]
 
 
+@pytest.mark.parametrize("cfg", [(2, 24, 40, 64, 96, 3, 1, 1), (3, 17, 21, 32, 64, 3, 1, 1), (2, 32, 64, 64, 96, 3, 2, 1),
+                                 (2, 32, 32, 96, 128, 1, 2, 0), (1, 64, 64, 3, 64, 7, 2, 3)])
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_conv2d_fused_instnorm(hip, cfg, prec):
+    """statistics from the conv epilogue == InstanceNorm of the conv output; in_stats == relu(IN(x)) applied up front."""
+    n, H, W, Cin, Cout, k, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + 1)
+    x = torch.randn(n, H, W, Cin, generator=g) * 1.5 + 0.3
+    w = torch.randn(Cout, k, k, Cin, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    if Cin == 3:
+        x4 = torch.zeros(n, H, W, 4)
+        x4[..., :3] = x
+        wt = torch.zeros(Cout, 7, 8, 4)
+        wt[:, :, :7, :3] = w
+        x, w, cin = x4, wt.reshape(Cout, 224), 4
+    else:
+        cin = Cin
+    hi, lo = split(hip, G(pad_w(w.reshape(Cout, -1))), prec == "bf16x3")
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    halo = k == 3 and s == 1
+    slots = hip.conv2d_stat_slots(H, W, cin, k, k, s, p)
+    assert slots == (((Ho + 7) // 8) * ((Wo + 15) // 16) * 4 if halo else Ho * Wo // 32)
+    xin = G(x)
+    in_st = None
+    if halo:  # normalise-on-load against an explicit normalise pass
+        in_st = torch.empty(n, cin, 2, device=DEV)
+        part64 = torch.empty(n * hip.IN_SLABS * cin * 2, device=DEV, dtype=torch.float64)
+        hip.instnorm_stats(xin, cin, part64, in_st, n, H * W, cin)
+        xn = torch.empty_like(xin)
+        hip.instnorm_apply(xin, in_st, None, None, xn, n, H * W, cin)
+    else:
+        xn = xin
+    ref = torch.empty(n, Ho, Wo, Cout, device=DEV)
+    hip.conv2d_bf16(xn, hi, lo, G(b), ref, n, H, W, cin, Cout, k, k, s, p, Cout)
+    out = torch.empty(n, Ho, Wo, Cout, device=DEV)
+    part = torch.full((n * slots * Cout * 2,), float("nan"), device=DEV)
+    hip.conv2d_bf16(xin, hi, lo, G(b), out, n, H, W, cin, Cout, k, k, s, p, Cout, in_stats=in_st, out_partial=part)
+    st = torch.empty(n, Cout, 2, device=DEV)
+    hip.instnorm_finish_slots(part, slots, st, n, Ho * Wo, Cout)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)  # same arithmetic on the same values
+    y = ref.double().reshape(n, Ho * Wo, Cout)
+    mean, var = y.mean(1), y.var(1, unbiased=False)
+    assert (st[..., 0].double() - mean).abs().max() < 1e-5
+    assert ((st[..., 1].double() * torch.sqrt(var + 1e-5)) - 1).abs().max() < 1e-5
+
+
 def test_split_bf16(hip):
     x = torch.randn(4096) * 3
     hi = torch.empty(4096, device=DEV, dtype=torch.int16)
