@@ -196,10 +196,18 @@ int mvt_unproject(const float* depth_s, const float* kinv, const float* einv, fl
  * indices per (query, slot) -- e.g. the previous iteration's neighbours (seed_cw == 0), or the neighbours found
  * on the next coarser pyramid level (seed_cw, seed_ch = coarse per-view grid; seed_fw, seed_fh = this level's
  * per-view grid; coarse (v,y,x) maps to (v,2y,2x)).  The scan then starts from the bound
- * max_j d2(query, seed_j) >= (K-th nearest distance) instead of +inf. */
+ * max_j d2(query, seed_j) >= (K-th nearest distance) instead of +inf.
+ * Optional tile culling (exactness preserved): the scan walks the cloud in tiles of 64 points and skips a tile
+ * whose bounding box (tile_box, from mvt_tile_aabb with the same grid_w/grid_h) lies farther than the current bound
+ * from all queries of the wave; the box distance is evaluated with the scan's own arithmetic, every rounding step
+ * of which is monotonic, so it never exceeds the d2 of a point inside the box.  grid_w = grid_h = 0: tile t = points
+ * [64t, 64t+64); grid_w, grid_h > 0 (multiples of 8, P = views*grid_h*grid_w in raster order): 8x8 pixel patches.
+ * The segments are runs of tiles; only the merged result (mvt_knn_merge) is layout independent. */
+int mvt_tile_aabb(const float* xyz, long long P, int T, int grid_w, int grid_h, float* box /* [T][ceil(P/64)][8] */,
+                  void* stream);
 int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step,
                  int T, int K, int nseg, unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw,
-                 int seed_ch, int seed_fw, int seed_fh, void* stream);
+                 int seed_ch, int seed_fw, int seed_fh, const float* tile_box, int grid_w, int grid_h, void* stream);
 /* Merge the nseg per-segment key lists of mvt_knn_scan: idx_out [N][S][K] int32 = the K nearest neighbour
  * indices, ascending by (d2, index); indices are clamped to [0, P) (only NaN queries can be out of range). */
 int mvt_knn_merge(const unsigned long long* keys, int N, int S, int K, int nseg, long long P, int* idx_out,

@@ -11,6 +11,8 @@
 //              gather the K neighbour rows (C floats each, two rows per 1-KiB wave load, all loads
 //              in flight together), dot them with the track feature by half-wave shuffle
 //              reductions, append the neighbour offsets.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -105,12 +107,57 @@ __device__ __forceinline__ unsigned long long rank_sort(const unsigned long long
   return out;
 }
 
+// Candidate tiles.  The scan visits the cloud 64 points (one wave load) at a time:
+//   linear tiles (grid_w == 0): tile t = points [64 t, 64 t + 64);
+//   patch tiles  (grid_w  > 0): the cloud is V images of grid_h x grid_w points in raster order (both multiples of 8) and
+//                               tile t is an 8x8 pixel patch - eight 128-byte row pieces - whose bounding box is compact.
+__device__ __forceinline__ long long tile_point(long long tile, int lane, int grid_w, int grid_h) {
+  if (grid_w == 0) return tile * 64 + lane;
+  const int tpr = grid_w >> 3, tpv = tpr * (grid_h >> 3);
+  const long long v = tile / tpv;
+  const int r = (int)(tile - v * tpv);
+  const int ty = r / tpr, tx = r - ty * tpr;
+  return (v * grid_h + ty * 8 + (lane >> 3)) * grid_w + tx * 8 + (lane & 7);
+}
+
+// box[frame][tile] = {lo.xyz, 0, hi.xyz, 0}; NaN points are ignored (fminf / fmaxf drop them), an all-NaN tile gets lo = +inf, hi = -inf
+__global__ __launch_bounds__(256) void tile_aabb_kernel(const float* __restrict__ xyz, long long P, long long ntiles, long long total,
+                                                        int grid_w, int grid_h, float* __restrict__ box) {
+  const int lane = threadIdx.x & 63;
+  const long long id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // frame * ntiles + tile
+  if (id >= total) return;
+  const long long frame = id / ntiles, tile = id - frame * ntiles;
+  const long long c = tile_point(tile, lane, grid_w, grid_h);
+  const float inf = __int_as_float(0x7f800000);
+  float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+  if (c < P) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(xyz + (frame * P + c) * 4);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      if (p[e] == p[e]) lo[e] = hi[e] = p[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[e] = fminf(lo[e], __shfl_xor(lo[e], o, 64));
+      hi[e] = fmaxf(hi[e], __shfl_xor(hi[e], o, 64));
+    }
+  }
+  if (lane == 0) {
+    float* b = box + id * 8;
+    *reinterpret_cast<f32x4*>(b) = (f32x4){lo[0], lo[1], lo[2], 0.f};
+    *reinterpret_cast<f32x4*>(b + 4) = (f32x4){hi[0], hi[1], hi[2], 0.f};
+  }
+}
+
 template <int Q>
 __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ xyz, long long P, const float* __restrict__ coords,
                                                        int N, int S, int frame0, int frame_step, int T, int K, int nseg,
                                                        unsigned long long* __restrict__ keys, int qgroups,
                                                        const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch,
-                                                       int seed_fw, int seed_fh) {
+                                                       int seed_fw, int seed_fh, const float* __restrict__ box, int grid_w, int grid_h) {
   __shared__ unsigned long long lds[4 * Q * CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // task id -> (segment, query group, slot); segment fastest so that heavy frames spread over CUs
@@ -123,9 +170,11 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   int frame = frame0 + s * frame_step;
   frame = frame < T - 1 ? frame : T - 1;
   const float* cand = xyz + (long long)frame * P * 4;
-  const long long per = (P + nseg - 1) / nseg;
-  const long long c0 = seg * per;
-  const long long c1 = c0 + per < P ? c0 + per : P;
+  const long long ntiles = (P + 63) >> 6;
+  const long long tper = (ntiles + nseg - 1) / nseg;
+  const long long t0 = seg * tper;
+  const long long t1 = t0 + tper < ntiles ? t0 + tper : ntiles;
+  const float* fbox = box ? box + (long long)frame * ntiles * 8 : nullptr;
 
   unsigned long long* list = lds + (long long)wave * Q * CAP;
   float qx[Q], qy[Q], qz[Q], thr[Q];
@@ -162,47 +211,75 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
     }
   }
   const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
+  const float qnan = __int_as_float(0x7fc00000);  // lanes past the cloud end carry NaN points: every compare fails
 
-  long long c = c0 + lane;
-  const float qnan = __int_as_float(0x7fc00000);  // lanes past the segment end carry NaN points: every compare fails
-  f32x4 p = (f32x4){qnan, qnan, qnan, 0.f};
-  if (c < c1) p = *reinterpret_cast<const f32x4*>(cand + c * 4);
-  for (long long base = c0; base < c1; base += 64) {
-    const long long cn = base + 64 + lane;
-    f32x4 pn = (f32x4){qnan, qnan, qnan, 0.f};
-    if (cn < c1) pn = *reinterpret_cast<const f32x4*>(cand + cn * 4);  // prefetch next step
-    float d2[Q];
-    unsigned long long m[Q];
-    unsigned long long any = 0;
-#pragma unroll
-    for (int i = 0; i < Q; ++i) {
-      const float dx = p[0] - qx[i], dy = p[1] - qy[i], dz = p[2] - qz[i];
-      d2[i] = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-      m[i] = __ballot(d2[i] <= thr[i]);
-      any |= m[i];
-    }
-    if (any) {  // rare after the warm-up: some query has a survivor in this step
+  auto load_tile = [&](long long tile, long long& c) {
+    c = tile_point(tile, lane, grid_w, grid_h);
+    f32x4 p = (f32x4){qnan, qnan, qnan, 0.f};
+    if (c < P) p = *reinterpret_cast<const f32x4*>(cand + c * 4);
+    return p;
+  };
+
+  for (long long tb = t0; tb < t1; tb += 64) {
+    // which of the next 64 tiles can hold a point within thr of any of the Q queries?  One tile per lane.  The bound
+    // uses the distance arithmetic of the scan itself on the per-axis gaps to the box, and every rounding step is
+    // monotonic, so bound <= d2 of every point in the box in floating point: a culled tile cannot hold a survivor.
+    const long long mt = tb + lane;
+    bool visit = mt < t1;
+    if (fbox && visit) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(fbox + mt * 8), hi = *reinterpret_cast<const f32x4*>(fbox + mt * 8 + 4);
+      bool near = false;
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
-        if (m[i]) {
-          unsigned long long* l = list + i * CAP;
-          if ((m[i] >> lane) & 1ULL) l[cnt[i] + __popcll(m[i] & lt_mask)] = ((unsigned long long)__float_as_uint(d2[i]) << 32) | (unsigned)c;
-          cnt[i] += __popcll(m[i]);
-          if (cnt[i] > CAP - 64) {
-            unsigned tb;
-            int nc = tighten(l, cnt[i], K, lane, lt_mask, &tb);
-            if (nc > CAP - 64) {  // > 48 exact distance ties at the threshold: resolve them by index now
-              select_k(l, nc, K, lane);
-              nc = K;
+        const float dx = fmaxf(fmaxf(lo[0] - qx[i], qx[i] - hi[0]), 0.f);
+        const float dy = fmaxf(fmaxf(lo[1] - qy[i], qy[i] - hi[1]), 0.f);
+        const float dz = fmaxf(fmaxf(lo[2] - qz[i], qz[i] - hi[2]), 0.f);
+        const float lb = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+        near = near || !(lb > thr[i]);  // NaN bound (NaN query): never cull
+      }
+      visit = near;
+    }
+    unsigned long long todo = __ballot(visit);
+    if (!todo) continue;
+    long long c, cn = 0;
+    f32x4 p = load_tile(tb + __builtin_ctzll(todo), c);
+    while (todo) {
+      todo &= todo - 1;
+      f32x4 pn = p;
+      if (todo) pn = load_tile(tb + __builtin_ctzll(todo), cn);  // prefetch the next surviving tile
+      float d2[Q];
+      unsigned long long m[Q];
+      unsigned long long any = 0;
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const float dx = p[0] - qx[i], dy = p[1] - qy[i], dz = p[2] - qz[i];
+        d2[i] = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+        m[i] = __ballot(d2[i] <= thr[i]);
+        any |= m[i];
+      }
+      if (any) {  // rare after the warm-up: some query has a survivor in this step
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+          if (m[i]) {
+            unsigned long long* l = list + i * CAP;
+            if ((m[i] >> lane) & 1ULL) l[cnt[i] + __popcll(m[i] & lt_mask)] = ((unsigned long long)__float_as_uint(d2[i]) << 32) | (unsigned)c;
+            cnt[i] += __popcll(m[i]);
+            if (cnt[i] > CAP - 64) {
+              unsigned tbits;
+              int nc = tighten(l, cnt[i], K, lane, lt_mask, &tbits);
+              if (nc > CAP - 64) {  // > 48 exact distance ties at the threshold: resolve them by index now
+                select_k(l, nc, K, lane);
+                nc = K;
+              }
+              cnt[i] = nc;
+              thr[i] = __uint_as_float(tbits);
             }
-            cnt[i] = nc;
-            thr[i] = __uint_as_float(tb);
           }
         }
       }
+      p = pn;
+      c = cn;
     }
-    p = pn;
-    c = cn;
   }
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
@@ -211,8 +288,8 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
     __builtin_amdgcn_wave_barrier();
     int nc = cnt[i];
     if (nc > K) {
-      unsigned tb;
-      nc = tighten(l, nc, K, lane, lt_mask, &tb);
+      unsigned tbits;
+      nc = tighten(l, nc, K, lane, lt_mask, &tbits);
     }
     unsigned long long v;
     if (nc <= 64) {
@@ -389,19 +466,43 @@ __global__ __launch_bounds__(256) void window_corr_kernel(const float* __restric
 
 }  // namespace
 
+extern "C" int mvt_tile_aabb(const float* xyz, long long P, int T, int grid_w, int grid_h, float* box, void* stream) {
+  MVT_REQUIRE(xyz && box && P > 0 && T > 0 && P < (1LL << 31));
+  MVT_REQUIRE((grid_w == 0 && grid_h == 0) || (grid_w > 0 && grid_h > 0 && grid_w % 8 == 0 && grid_h % 8 == 0 && P % ((long long)grid_w * grid_h) == 0));
+  const long long ntiles = (P + 63) / 64, total = ntiles * T;
+  hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)mvt_cdiv(total, 4)), dim3(256), 0, mvt_stream(stream), xyz, P, ntiles, total, grid_w,
+                     grid_h, box);
+  return mvt_launch_status();
+}
+
 extern "C" int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step, int T,
                             int K, int nseg, unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw, int seed_ch,
-                            int seed_fw, int seed_fh, void* stream) {
+                            int seed_fw, int seed_fh, const float* tile_box, int grid_w, int grid_h, void* stream) {
   MVT_REQUIRE(!seed_idx || (seed_k >= K && seed_k <= 64 && seed_cw >= 0));
   MVT_REQUIRE(!seed_idx || seed_cw == 0 || (seed_ch > 0 && seed_fw >= 2 * seed_cw && seed_fh >= 2 * seed_ch));
   MVT_REQUIRE(xyz && coords && keys && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0);
-  MVT_REQUIRE(K >= 1 && K <= 16 && nseg >= 1 && nseg * K <= 64 && P < (1LL << 31));
-  MVT_REQUIRE((P + nseg - 1) / nseg >= K && ((P + nseg - 1) / nseg) * (nseg - 1) + K <= P);  // every segment holds >= K points
-  constexpr int Q = 8;
+  MVT_REQUIRE(K >= 1 && K <= 16 && nseg >= 1 && nseg * K <= 64 && P < (1LL << 31) && P >= K);
+  MVT_REQUIRE((grid_w == 0 && grid_h == 0) || (grid_w > 0 && grid_h > 0 && grid_w % 8 == 0 && grid_h % 8 == 0 && P % ((long long)grid_w * grid_h) == 0));
+  const long long ntiles = (P + 63) / 64, tper = (ntiles + nseg - 1) / nseg;
+  MVT_REQUIRE(tper * (nseg - 1) < ntiles);  // no empty segment (a short one pads its key list with KEY_MAX)
+  // queries per wave: 8 amortise the point loads of a brute-force scan; with boxes the scan is short and the per-query
+  // selection work dominates, which spreads better over many small waves
+  static const int q_env = getenv("MVT_KNN_Q") ? atoi(getenv("MVT_KNN_Q")) : 0;
+  const int Q = q_env ? q_env : (tile_box ? 2 : 8);
   const int qgroups = (N + Q - 1) / Q;
   const long long ntask = (long long)qgroups * S * nseg;
-  hipLaunchKernelGGL((knn_scan_kernel<Q>), dim3((unsigned)mvt_cdiv(ntask, 4)), dim3(256), 0, mvt_stream(stream), xyz, P, coords, N, S,
-                     frame0, frame_step, T, K, nseg, keys, qgroups, seed_idx, seed_k, seed_cw, seed_ch, seed_fw, seed_fh);
+#define LAUNCH(QQ)                                                                                                                   \
+  hipLaunchKernelGGL((knn_scan_kernel<QQ>), dim3((unsigned)mvt_cdiv(ntask, 4)), dim3(256), 0, mvt_stream(stream), xyz, P, coords, N, S, \
+                     frame0, frame_step, T, K, nseg, keys, qgroups, seed_idx, seed_k, seed_cw, seed_ch, seed_fw, seed_fh, tile_box,    \
+                     grid_w, grid_h)
+  switch (Q) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    default: return MVT_ERR_ARG;
+  }
+#undef LAUNCH
   return mvt_launch_status();
 }
 

@@ -47,7 +47,8 @@ SIGNATURES = {
     "mvt_depth_subsample": [P, P, I, I, I, I, I, P],
     "mvt_avgpool2": [P, P, LL, I, I, I, P],
     "mvt_unproject": [P, P, P, P, I, I, I, I, I, I, P],
-    "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P],
+    "mvt_tile_aabb": [P, LL, I, I, I, P, P],
+    "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P, I, I, P],
     "mvt_knn_merge": [P, I, I, I, I, LL, P, P],
     "mvt_corr_gather_dot": [I, P, P, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
     "mvt_knn1_gather": [P, LL, I, P, I, I, I, P, P, P],
@@ -210,10 +211,17 @@ def unproject(depth_s, kinv, einv, xyz, V, T, hs, ws, stride, level):
     _call("mvt_unproject", _ptr(depth_s), _ptr(kinv), _ptr(einv), _ptr(xyz), V, T, hs, ws, stride, level, _stream())
 
 
-def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_idx=None, seed_k=0, seed_dims=(0, 0, 0, 0)):
-    """seed_dims = (coarse_w, coarse_h, fine_w, fine_h) per-view grids when the seed comes from the coarser level."""
+def tile_aabb(xyz, Pn, T, box, grid=(0, 0)):
+    """box (T, ceil(Pn/64), 8) <- bounding boxes of the 64-point tiles; grid = per-view (w, h) for 8x8 patch tiles."""
+    _call("mvt_tile_aabb", _ptr(xyz), Pn, T, grid[0], grid[1], _ptr(box), _stream())
+
+
+def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_idx=None, seed_k=0, seed_dims=(0, 0, 0, 0), box=None,
+             grid=(0, 0)):
+    """seed_dims = (coarse_w, coarse_h, fine_w, fine_h) per-view grids when the seed comes from the coarser level;
+    box / grid: tile bounding boxes from ``tile_aabb`` (same grid) for culling."""
     _call("mvt_knn_scan", _ptr(xyz), Pn, _ptr(coords), N, S, frame0, frame_step, T, K, nseg, _ptr(keys), _ptr(seed_idx), seed_k,
-          *seed_dims, _stream())
+          *seed_dims, _ptr(box), grid[0], grid[1], _stream())
 
 
 def knn_merge(keys, N, S, K, nseg, Pn, idx_out):

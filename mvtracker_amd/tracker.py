@@ -372,11 +372,22 @@ class MVTracker(nn.Module):
             hip.unproject(ds, kinv, einv, o, V, T, hs, ws, self.stride, lvl)
             xyz.append(o)
         P = [V * (hs >> lvl) * (ws >> lvl) for lvl in range(self.corr_n_levels)]
-        return {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds}
+        # bounding boxes of the 64-point scan tiles (8x8 pixel patches where the grid allows it): the kNN scan culls with them
+        box, tgrid = [], []
+        for lvl in range(self.corr_n_levels):
+            h, w = hs >> lvl, ws >> lvl
+            g = (w, h) if (w % 8 == 0 and h % 8 == 0) else (0, 0)
+            b = torch.empty(T, (P[lvl] + 63) // 64, 8, device=dev)
+            hip.tile_aabb(xyz[lvl], P[lvl], T, b, g)
+            box.append(b)
+            tgrid.append(g)
+        return {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds, "box": box, "tile_grid": tgrid}
 
     def _nseg(self, P: int, K: int) -> int:
+        """Segments (runs of 64-point tiles) scanned by different waves; none may be empty."""
+        nt = (P + 63) // 64
         n = max(1, min(64 // K, P // 8192, 4))
-        while n > 1 and ((P + n - 1) // n) * (n - 1) + K > P:
+        while n > 1 and ((nt + n - 1) // n) * (n - 1) >= nt:
             n -= 1
         return n
 
@@ -583,7 +594,8 @@ class MVTracker(nn.Module):
                     seed = dict(seed_idx=idx[lvl], seed_k=K)
                 elif lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
                     seed = dict(seed_idx=idx[lvl + 1], seed_k=K, seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
-                hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl], **seed)
+                hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl], box=store["box"][lvl],
+                             grid=store["tile_grid"][lvl], **seed)
                 hip.knn_merge(keys[lvl], n, S, K, nsegs[lvl], P, idx[lvl])
             hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0, 1,
                                 T, K, fcorr, Fc, 0)
@@ -680,7 +692,8 @@ class MVTracker(nn.Module):
                     b = int(np.searchsorted(qt_s, t, side="right"))
                     b = min(b, p1)
                     keys = torch.empty((b - a) * ns, device=dev, dtype=torch.int64)
-                    hip.knn_scan(store["xyz"][0], P0, qxyz[a:b], b - a, 1, t, 0, T, 1, ns, keys)
+                    hip.knn_scan(store["xyz"][0], P0, qxyz[a:b], b - a, 1, t, 0, T, 1, ns, keys, box=store["box"][0],
+                                 grid=store["tile_grid"][0])
                     hip.knn1_gather(store["fvec"][0], P0, C, keys, b - a, ns, t, feat_init[a:b])
                     a = b
             if p0 > 0:  # carry-over from the previous window (:648-655); vis is the previous LOGIT

@@ -239,8 +239,13 @@ def _d2(ref, q):
     return (dz * dz + acc.double()).float()
 
 
-def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_idx=None, seed_k=0, seed_dims=(0, 0, 0, 0)):
-    # the seed only prunes; the result is the exact kNN either way.  Check the seed contract: valid distinct indices.
+def tile_aabb(xyz, Pn, T, box, grid=(0, 0)):
+    box.zero_()  # culling only prunes: the mock scan ignores the boxes
+
+
+def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_idx=None, seed_k=0, seed_dims=(0, 0, 0, 0), box=None,
+             grid=(0, 0)):
+    # the seed / boxes only prune; the result is the exact kNN either way.  Check the seed contract: valid distinct indices.
     if seed_idx is not None:
         si = seed_idx.reshape(N, S, seed_k).long()
         cw, ch, fw, fh = seed_dims
@@ -252,14 +257,16 @@ def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_i
     X = torch.as_strided(xyz, (T, Pn, 4), (Pn * 4, 4, 1))
     c = torch.as_strided(coords, (N, S, 3), (S * 3, 3, 1))
     kv = torch.as_strided(keys, (N, S, nseg, K), (S * nseg * K, nseg * K, K, 1))
-    per = (Pn + nseg - 1) // nseg
+    per = ((Pn + 63) // 64 + nseg - 1) // nseg * 64
+    kv.fill_(torch.iinfo(torch.int64).max)  # pads a short segment (sorts last, like the library's KEY_MAX)
     for s in range(S):
         f = min(frame0 + s * frame_step, T - 1)
         d2 = _d2(X[f, :, :3], c[:, s])
         key = (d2.view(torch.int32).to(torch.int64) << 32) | torch.arange(Pn)[None]
         for g in range(nseg):
             seg = key[:, g * per:min(Pn, (g + 1) * per)]
-            kv[:, s, g] = torch.topk(seg, K, dim=1, largest=False, sorted=True).values
+            kk = min(K, seg.shape[1])
+            kv[:, s, g, :kk] = torch.topk(seg, kk, dim=1, largest=False, sorted=True).values
 
 
 def knn_merge(keys, N, S, K, nseg, Pn, idx_out):
@@ -366,6 +373,6 @@ def install(monkeypatch):
     from mvtracker_amd import hip
     me = sys.modules[__name__]
     for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
-                 "depth_subsample avgpool2 unproject knn_scan knn_merge corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
+                 "depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

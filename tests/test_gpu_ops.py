@@ -417,6 +417,52 @@ def test_knn_seeded_scan_is_exact(hip):
     assert torch.equal(idx2, ref)
 
 
+@pytest.mark.parametrize("patch", [False, True])
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_knn_tile_culling_is_exact(hip, patch, nseg):
+    """Bounding-box culling (linear and 8x8-patch tiles), with and without a seed, with NaN points and NaN / far queries:
+    neighbour indices equal the oracle's bit for bit."""
+    g = torch.Generator().manual_seed(21 + nseg)
+    V, h, w, K, M, B = 3, 24, 40, 16, 45, 2
+    P = V * h * w
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    base = torch.stack([xs * 0.05, ys * 0.05, 0.3 * torch.sin(xs * 0.2) + 0.1 * ys], -1).reshape(1, 1, h * w, 3)
+    xyz = (base + torch.rand(B, V, h * w, 3, generator=g) * 0.02 + torch.arange(V).view(1, V, 1, 1) * 0.017).reshape(B, P, 3)
+    xyz[0, 100:180] = float("nan")        # invalid points, including one whole linear tile (128..191 partially) ...
+    xyz[1, 64 * 5:64 * 6] = float("nan")  # ... and exactly one all-NaN linear tile
+    q = torch.rand(B, M, 3, generator=g) * torch.tensor([2.0, 1.2, 2.5])
+    q[:, 0] = torch.tensor([50.0, -30.0, 9.0])  # far outside every box
+    x4 = torch.zeros(B, P, 4)
+    x4[..., :3] = xyz
+    x4g, cd = G(x4), G(q.permute(1, 0, 2))
+    grid = (w, h) if patch else (0, 0)
+    box = torch.empty(B, (P + 63) // 64, 8, device=DEV)
+    hip.tile_aabb(x4g, P, B, box, grid)
+    torch.cuda.synchronize()
+    if not patch:  # boxes against a direct evaluation
+        t = xyz[:, :(P // 64) * 64].reshape(B, P // 64, 64, 3)
+        lo = torch.where(torch.isnan(t), torch.full_like(t, float("inf")), t).amin(2)
+        hi = torch.where(torch.isnan(t), torch.full_like(t, float("-inf")), t).amax(2)
+        assert torch.equal(box[:, :P // 64, 0:3].cpu(), lo) and torch.equal(box[:, :P // 64, 4:7].cpu(), hi)
+    _, ref = O.knn_exact(K, torch.where(torch.isnan(xyz), torch.full_like(xyz, 1e18), xyz), q)
+
+    def run(**kw):
+        keys = torch.empty(M * B * nseg * K, device=DEV, dtype=torch.int64)
+        hip.knn_scan(x4g, P, cd, M, B, 0, 1, B, K, nseg, keys, box=box, grid=grid, **kw)
+        idx = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
+        hip.knn_merge(keys, M, B, K, nseg, P, idx)
+        torch.cuda.synchronize()
+        return idx
+
+    idx = run()
+    assert torch.equal(idx.permute(1, 0, 2).cpu().long(), ref)
+    q2 = q + torch.randn(B, M, 3, generator=g) * 0.01
+    cd = G(q2.permute(1, 0, 2))
+    _, ref2 = O.knn_exact(K, torch.where(torch.isnan(xyz), torch.full_like(xyz, 1e18), xyz), q2)
+    idx2 = run(seed_idx=idx, seed_k=K)
+    assert torch.equal(idx2.permute(1, 0, 2).cpu().long(), ref2)
+
+
 def test_corr_all_levels_one_launch(hip):
     g = torch.Generator().manual_seed(12)
     B, M, K, C = 2, 30, 16, 128

@@ -103,6 +103,15 @@ if "knn" in which:
         hip.knn_merge(keys, N, S, K, nseg, P, idx)
         q2 = q + torch.randn_like(q) * 0.002
         t1 = timeit(lambda: hip.knn_scan(xyz, P, q2, N, S, 0, 1, T, K, nseg, keys, seed_idx=idx, seed_k=K), iters=5, warm=1)
+        box = torch.empty(T, (P + 63) // 64, 8, device="cuda")
+        hip.tile_aabb(xyz, P, T, box)
+        t2 = timeit(lambda: hip.knn_scan(xyz, P, q2, N, S, 0, 1, T, K, nseg, keys, seed_idx=idx, seed_k=K, box=box), iters=5, warm=1)
+        boxp = torch.empty(T, (P + 63) // 64, 8, device="cuda")
+        hip.tile_aabb(xyz, P, T, boxp, (hw, hw))
+        t3 = timeit(lambda: hip.knn_scan(xyz, P, q2, N, S, 0, 1, T, K, nseg, keys, seed_idx=idx, seed_k=K, box=boxp, grid=(hw, hw)), iters=5, warm=1)
+        t4 = timeit(lambda: hip.knn_scan(xyz, P, q2, N, S, 0, 1, T, K, 1, keys, seed_idx=idx, seed_k=K, box=boxp, grid=(hw, hw)), iters=5, warm=1)
+        t5 = timeit(lambda: hip.knn_scan(xyz, P, q, N, S, 0, 1, T, K, nseg, keys, box=boxp, grid=(hw, hw)), iters=5, warm=1)
+        print(f"  seeded + culling: linear tiles {t2:.1f} us, 8x8 patches {t3:.1f} us (nseg=1: {t4:.1f} us); unseeded + patches {t5:.1f} us")
         pairs = N * S * P
         print(f"knn P={P} nseg={nseg}: unseeded {t0:.0f} us ({pairs / t0 / 1e3:.0f} Gpair/s)  seeded {t1:.0f} us ({pairs / t1 / 1e3:.0f} Gpair/s)")
 
