@@ -107,6 +107,8 @@ class MVTracker(nn.Module):
         self.fuse_mlp = True
         self.fuse_blocks = True
         self.mfma_attention = True
+        self.overlap_encoder = os.environ.get("MVT_OVERLAP", "1") != "0"  # encode later frames on a second stream
+        self._side = {}
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
         d = self.updateformer_input_dim
@@ -330,13 +332,14 @@ class MVTracker(nn.Module):
         self._inorm(y, n, hs * ws, 2 * C, st=st)
         self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C)
 
-    def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16):
-        """rgbs (V,T,3,H,W) in [0,255] -> level-0 features (T,V,H/4,W/4,C); frames outside [t0,t1) are left zero."""
+    def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16, out=None):
+        """rgbs (V,T,3,H,W) in [0,255] -> level-0 features (T,V,H/4,W/4,C); frames outside [t0,t1) are left zero
+        (or untouched when the result goes into ``out``)."""
         V, T, _, H, W = rgbs.shape
         t1 = T if t1 is None else t1
         pk = self._pack(rgbs.device)
         hs, ws = H // self.stride, W // self.stride
-        F0 = torch.zeros(T, V, hs, ws, self.latent_dim, device=rgbs.device)
+        F0 = out if out is not None else torch.zeros(T, V, hs, ws, self.latent_dim, device=rgbs.device)
         step = max(1, images_per_chunk // V)
         for a in range(t0, t1, step):
             nt = min(step, t1 - a)
@@ -346,21 +349,39 @@ class MVTracker(nn.Module):
         return F0
 
     # ------------------------------------------------------------------ frame store (model_utils.py:420-482)
-    def build_frame_store(self, rgbs, depths, intrs, extrs, t0=0, level0=None):
+    def _side_stream(self, dev):
+        key = (dev.type, dev.index)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
+    def fill_frame_features(self, store, rgbs, a, b, level0=None):
+        """Encode frames [a, b) into the store's feature pyramid (everything else in the store is geometry)."""
+        V, T, _, H, W = rgbs.shape
+        hs, ws = H // self.stride, W // self.stride
+        fv = store["fvec"]
+        if level0 is None:
+            self.encode_frames(rgbs, a, b, images_per_chunk=max(16, V * (self.S // 2)), out=fv[0])
+        for lvl in range(1, self.corr_n_levels):
+            h, w = hs >> (lvl - 1), ws >> (lvl - 1)
+            hip.avgpool2(fv[lvl - 1][a:b], fv[lvl][a:b], (b - a) * V, h, w, self.latent_dim)
+
+    def build_frame_store(self, rgbs, depths, intrs, extrs, t0=0, level0=None, t1=None):
         """Features and world-space points of every pyramid level, frame-major.
 
         rgbs (V,T,3,H,W), depths (V,T,1,H,W), intrs (V,T,3,3), extrs (V,T,3,4).  ``level0`` (T,V,H/4,W/4,C)
-        may carry level-0 features encoded elsewhere (frames split across GPUs, mvtracker_amd.parallel)."""
+        may carry level-0 features encoded elsewhere (frames split across GPUs, mvtracker_amd.parallel).
+        Features are computed for frames [t0, t1) only (``fill_frame_features`` adds more later); the geometry
+        (points, tile boxes) covers every frame."""
         V, T, _, H, W = rgbs.shape
         dev = rgbs.device
         hs, ws = H // self.stride, W // self.stride
         C = self.latent_dim
-        fv = [self.encode_frames(rgbs, t0) if level0 is None else level0]
+        t1 = T if t1 is None else t1
+        fv = [torch.zeros(T, V, hs, ws, C, device=dev) if level0 is None else level0]
         for lvl in range(1, self.corr_n_levels):
-            h, w = hs >> (lvl - 1), ws >> (lvl - 1)
-            nxt = torch.zeros(T, V, h // 2, w // 2, C, device=dev)
-            hip.avgpool2(fv[-1][t0:], nxt[t0:], (T - t0) * V, h, w, C)
-            fv.append(nxt)
+            fv.append(torch.zeros(T, V, hs >> lvl, ws >> lvl, C, device=dev))
+        self.fill_frame_features({"fvec": fv}, rgbs, t0, t1, level0)
         kinv = torch.empty(V * T, 9, device=dev)
         einv = torch.empty(V * T, 12, device=dev)
         hip.invert_cameras(intrs.reshape(V * T, 9), extrs.reshape(V * T, 12), kinv, einv, V * T)
@@ -675,13 +696,34 @@ class MVTracker(nn.Module):
 
         w = int(qt_s.min())
         windows = []
+        pending = []  # (first frame, event): feature chunks being encoded on the side stream
         if w < T - S // 2:
-            store = frame_store if frame_store is not None else self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0))
+            if frame_store is not None:
+                store = frame_store
+            elif not self.overlap_encoder or max(w, 0) + S >= T or dev.type != "cuda":
+                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0))
+            else:
+                # The first window needs frames [w, w+S).  The remaining frames are encoded on a second HIP stream while
+                # the updater of the earlier windows runs: its kernels over the 64 virtual tracks fill a fraction of the
+                # CUs, the encoder's convolutions take the rest.
+                ready = max(w, 0) + S
+                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), t1=ready)
+                main = torch.cuda.current_stream(dev)
+                side = self._side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    for a in range(ready, T, S // 2):
+                        self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        pending.append((a, ev))
         p0 = 0
         coords = vis = None
         while w < T - S // 2:  # mvtracker.py:537
             p1 = int(np.searchsorted(qt_s, w + S, side="left"))  # number of queries with t < w+S (:538-540)
             assert p1 > 0
+            while pending and pending[0][0] < w + S:  # the frames this window reads must have left the encoder
+                torch.cuda.current_stream(dev).wait_event(pending.pop(0)[1])
             S_local = min(S, T - w)
             if p1 > p0:  # feature init: 1-NN in the fused level-0 cloud of the query frame (:607-645)
                 P0 = store["P"][0]
@@ -719,6 +761,8 @@ class MVTracker(nn.Module):
             windows.append((w, p1))
             w += S // 2
             p0 = p1
+        for _, ev in pending:  # frames no window consumed: still join the side stream before the inputs are released
+            torch.cuda.current_stream(dev).wait_event(ev)
         self.last_windows = windows
         self.last_vis_logits = vis_logit[:, inv_d][None]
         self.last_nan_flag = nan_flag
