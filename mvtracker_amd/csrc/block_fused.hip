@@ -29,15 +29,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int NT = 512;   // threads (8 waves)
 constexpr int C = 256;    // hidden size of the updater
 constexpr int LDX = C + 8;
-// NMB = 32-row token blocks per workgroup.  NMB = 4 (128 rows, MLP chunks of 128 hidden units) for the 12k point rows;
-// NMB = 1 (32 rows, chunks of 256) for the 768 virtual-token rows, where the kernel is pure weight streaming and the
-// work has to be spread over as many CUs as possible.
+// NMB = 32-row token blocks per workgroup: 2 (64 rows) for the 12k point rows, 1 (32 rows) for the 768 virtual-token
+// rows, where the work has to be spread over as many CUs as possible.  (128-row workgroups leave most CUs idle at
+// M = 12288 and measured 1.6x slower.)
 template <int NMB> struct Cfg {
   static constexpr int BM = 32 * NMB;
-  static constexpr int HC = NMB == 4 ? 128 : 256;       // MLP hidden units per chunk
+  static constexpr int HC = 256;                         // MLP hidden units per chunk
   static constexpr int JW = HC / 32;                     // waves across the hidden blocks of a chunk (4 or 8)
   static constexpr int NM1 = NMB / (8 / JW);             // token blocks per wave in fc1 (2 or 1)
-  static constexpr int LDH = NMB == 4 ? 152 : HC + 8;    // bf16 row stride of the H buffers
+  static constexpr int LDH = HC + 8;                     // bf16 row stride of the H buffers
   static constexpr int LDA = 296;                        // attention tile row stride (Ko = 288)
   static_assert(BM * LDA <= 2 * BM * LDH, "attention tile fits the H buffers");
 };
@@ -106,23 +106,55 @@ __device__ __forceinline__ void gemm_wt(f32x16 (&acc)[NMB], const unsigned short
 // Same product with a persistent weight-fragment queue: wq holds the first PFQ fragments of this stream on entry and the
 // first PFQ fragments of the NEXT stream (nxt -> its row, 8h already applied) on exit, so the global-load latency of
 // every GEMM call hides under the previous call instead of being exposed at its start.  KS % PFQ == 0.
-constexpr int PFQ = 8;
+constexpr int PFQ = 16;
 template <int KS, int NMB>
 __device__ __forceinline__ void gemm_wq(f32x16 (&acc)[NMB], bf16x8 (&wq)[PFQ], const unsigned short* wrow, const unsigned short* nxt,
                                         const unsigned short* arow, int lda, int mb0) {
-  static_assert(KS % PFQ == 0, "chained streams need whole groups");
-#pragma unroll 1
-  for (int g = 0; g < KS / PFQ; ++g) {
+  static_assert(KS == PFQ, "every GEMM segment is exactly one queue length");
+  // Activation fragments are read from LDS one group of GK k-steps ahead of the MFMAs that use them (double-buffered
+  // registers): the ~130-cycle LDS latency hides under the previous group's MFMAs instead of being paid per group.
+  constexpr int GK = NMB >= 2 ? 2 : 4;
+  bf16x8 xa[GK][NMB], xn[GK][NMB];
 #pragma unroll
-    for (int j = 0; j < PFQ; ++j) {
-      const int ks = g * PFQ + j;
-      const bf16x8 wa = wq[j];
-      wq[j] = ldg_frag(ks + PFQ < KS ? wrow + (ks + PFQ) * FS : nxt + (ks + PFQ - KS) * FS);
+  for (int j = 0; j < GK; ++j)
+#pragma unroll
+    for (int i = 0; i < NMB; ++i) xa[j][i] = lds_frag(arow + (mb0 + i) * 32 * lda + j * 16);
+#pragma unroll
+  for (int g = 0; g < KS / GK; ++g) {
+    if (g + 1 < KS / GK) {
+#pragma unroll
+      for (int j = 0; j < GK; ++j)
+#pragma unroll
+        for (int i = 0; i < NMB; ++i) xn[j][i] = lds_frag(arow + (mb0 + i) * 32 * lda + ((g + 1) * GK + j) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < GK; ++j) {
+      const int ks = g * GK + j;
+      const bf16x8 wa = wq[ks];
+#ifndef MVT_ABL_NOLOAD
+      wq[ks] = ldg_frag(nxt + ks * FS);
+#endif
 #pragma unroll
       for (int i = 0; i < NMB; ++i) {
-        const bf16x8 xb = lds_frag(arow + (mb0 + i) * 32 * lda + ks * 16);
+#ifdef MVT_ABL_NOLDS
+        const bf16x8 xb = wa;
+#else
+        const bf16x8 xb = xa[j][i];
+#endif
+#ifdef MVT_ABL_NOMFMA
+        acc[i][0] += (float)xb[0] + (float)wa[1];
+#else
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[i], 0, 0, 0);
+#endif
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < KS / GK) {
+#pragma unroll
+      for (int j = 0; j < GK; ++j)
+#pragma unroll
+        for (int i = 0; i < NMB; ++i) xa[j][i] = xn[j][i];
     }
   }
 }
@@ -233,8 +265,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     }
   }
 
-  // ---- 2. MLP: LayerNorm -> Xs, then chunks of 128 hidden units.  x (after the projection) is parked in global memory
-  //         during the chunk loop so that its 64 registers are free for the accumulators.
+  // ---- 2. MLP: LayerNorm -> Xs, then chunks of HC hidden units.  x stays in registers: parking it in global memory
+  //         (a store plus two dependent re-reads per token) cost more HBM traffic than the whole GEMM loop took.
   auto store_x = [&]() {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
@@ -250,8 +282,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
     }
   };
-  if (p.att) store_x();
   ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
+  bf16x8 wq[PFQ];  // the weight-fragment queue, chained through the MLP and the follow-up projections
+  const bool tail_next = p.n_next > 0 && wave < (p.next[0].N + 31) / 32;
   {
     f32x16 acc2[NMB];
 #pragma unroll
@@ -262,21 +295,23 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     const int jb = wave % JW, mp = wave / JW;
     const int nchunk = p.H / HC;
     const unsigned short* w1row = p.w1 + ((long long)jb * (C / 16) * 64 + lane) * 8;                 // + c * 4 blocks
-    const unsigned short* w2row = p.w2 + ((long long)wave * (p.H / 16) * 64 + lane) * 8;             // + c * 8 k-steps
-    bf16x8 q1[PFQ], q2[PFQ];
-    fill_wq(q1, w1row);
-    fill_wq(q2, w2row);
+    const unsigned short* w2row = p.w2 + ((long long)wave * (p.H / 16) * 64 + lane) * 8;             // + c * (HC/16) k-steps
+    static_assert(HC / 16 == PFQ && C / 16 == PFQ, "every GEMM segment is exactly one queue length");
+    const unsigned short* tail = tail_next ? p.next[0].w + ((long long)wave * (C / 16) * 64 + lane) * 8 : w1row;
+    // ONE fragment queue for the whole MLP: the wave consumes fc1(c0), fc2(c0), fc1(c1), ... strictly in this order, 16
+    // k-steps each, so the queue always holds the next 16 fragments of that sequence (>= 16 MFMA k-steps of lookahead,
+    // which is what an L2 round trip needs; two half-depth queues left every fragment ~250 cycles short)
+    fill_wq(wq, w1row);
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
       unsigned short* Hb = Hs[c & 1];
-      const int cn = c + 1 < nchunk ? c + 1 : c;  // the last chunk prefetches itself again (harmless)
-      // fc1: H^T block (hidden jb of this chunk) x token blocks 2mp, 2mp+1
+      // fc1: H^T block (hidden jb of this chunk) x token blocks NM1*mp ..
       f32x16 ha[NM1];
 #pragma unroll
       for (int i = 0; i < NM1; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ha[i][e] = 0.f;
-      gemm_wq<C / 16, NM1>(ha, q1, w1row + (long long)c * JW * (C / 16) * FS, w1row + (long long)cn * JW * (C / 16) * FS, &Xs[r * LDX + 8 * h], LDX,
+      gemm_wq<C / 16, NM1>(ha, wq, w1row + (long long)c * JW * (C / 16) * FS, w2row + (long long)c * (HC / 16) * FS, &Xs[r * LDX + 8 * h], LDX,
                            NM1 * mp);
 #pragma unroll
       for (int i = 0; i < NM1; ++i) {
@@ -290,56 +325,47 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
       }
       __syncthreads();
-      // fc2 partial: out^T block (channels of this wave) += W2[:, chunk] . H^T
-      gemm_wq<HC / 16, NMB>(acc2, q2, w2row + (long long)c * (HC / 16) * FS, w2row + (long long)cn * (HC / 16) * FS, &Hb[r * LDH + 8 * h], LDH, 0);
+      // fc2 partial: out^T block (channels of this wave) += W2[:, chunk] . H^T; refills the queue with the next chunk's fc1
+      // fragments (after the last chunk: with the first follow-up projection's, or harmlessly with fc1(c0) again)
+      const unsigned short* after = c + 1 < nchunk ? w1row + (long long)(c + 1) * JW * (C / 16) * FS : tail;
+      gemm_wq<HC / 16, NMB>(acc2, wq, w2row + (long long)c * (HC / 16) * FS, after, &Hb[r * LDH + 8 * h], LDH, 0);
     }
-    // x = x (parked) + MLP output
+    // x += MLP output
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb) {
-      const long long m = m0 + mb * 32 + r;
+    for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (m < p.M) xv = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[mb][4 * g + e] = xv[e] + acc2[mb][4 * g + e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
-      }
-    }
+        for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += acc2[mb][4 * g + e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
   }
   store_x();
 
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
+  bool have = tail_next;  // the queue already holds this wave's first block of the projection
 #pragma unroll
   for (int q = 0; q < 2; ++q) {  // static indices: a dynamically indexed kernel-argument array would live in scratch
     if (q >= p.n_next) break;
     const mvt_block_next nx = p.next[q];
     __syncthreads();  // every wave is done reading Xs / Hs
-    {  // x is re-read (this thread stored it above) so that nothing but the accumulators is live during the GEMM
-      f32x16 xv[NMB];
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) {
-        const long long m = m0 + mb * 32 + r;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 t4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (m < p.M) t4 = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xv[mb][4 * g + e] = t4[e];
-        }
-      }
-      ln_to_lds<NMB>(xv, Xs, st, wave, lane, nx.eps, nx.lnw, nx.lnb);
-    }
+    // the projection's bias goes through LDS (b1s is free after the MLP; N <= 4C): a global load in the epilogue would sit
+    // behind the 16 queued fragment loads in the in-order vmcnt counter and expose their whole latency every block
+    for (int i = t; i < nx.N; i += NT) b1s[i] = nx.b[i];
+    ln_to_lds<NMB>(v, Xs, st, wave, lane, nx.eps, nx.lnw, nx.lnb);
     const int nblocks = (nx.N + 31) / 32;
     auto nrow_of = [&](int nb) { return nx.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
-    bf16x8 qn[PFQ];
-    if (wave < nblocks) fill_wq(qn, nrow_of(wave));
+    if (wave < nblocks && !have) fill_wq(wq, nrow_of(wave));
+    // after this wave's last block the queue moves on to its first block of the next projection, if there is one
+    const unsigned short* chain = nullptr;
+    if (q + 1 < p.n_next && wave < (p.next[q + 1 < 2 ? q + 1 : 1].N + 31) / 32)
+      chain = p.next[q + 1 < 2 ? q + 1 : 1].w + ((long long)wave * (C / 16) * 64 + lane) * 8;
+    have = chain != nullptr && wave < nblocks;
     for (int nb = wave; nb < nblocks; nb += 8) {
       f32x16 acc[NMB];
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
-      gemm_wq<C / 16, NMB>(acc, qn, nrow_of(nb), nrow_of(nb + 8 < nblocks ? nb + 8 : nb), &Xs[r * LDX + 8 * h], LDX, 0);
+      gemm_wq<C / 16, NMB>(acc, wq, nrow_of(nb), nb + 8 < nblocks ? nrow_of(nb + 8) : (chain ? chain : nrow_of(nb)), &Xs[r * LDX + 8 * h], LDX, 0);
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
         const long long m = m0 + mb * 32 + r;
@@ -350,12 +376,12 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
           if (n + 3 < nx.N) {
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[mb][4 * g + e] + nx.b[n + e];
+            for (int e = 0; e < 4; ++e) o[e] = acc[mb][4 * g + e] + b1s[n + e];
             *reinterpret_cast<f32x4*>(nx.y + m * (long long)nx.ldy + n) = o;
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (n + e < nx.N) nx.y[m * (long long)nx.ldy + n + e] = acc[mb][4 * g + e] + nx.b[n + e];
+              if (n + e < nx.N) nx.y[m * (long long)nx.ldy + n + e] = acc[mb][4 * g + e] + b1s[n + e];
           }
         }
       }
@@ -405,15 +431,13 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const float* att, int lda
   a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.ldw1 = ldw1; a.ldw2 = ldw2; a.H = H; a.M = M; a.n_next = n_next;
   for (int q = 0; q < n_next; ++q) {
     const mvt_block_next& nx = next[q];
-    MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
+    MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
     MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
     a.next[q] = nx;
   }
   static const char* force = getenv("MVT_BLOCK_NMB");  // tuning override
   const int nmb = force ? atoi(force) : (M >= 4096 ? 2 : 1);  // 64-row workgroups measured 1.6x faster than 128-row ones at M = 12288
-  if (nmb == 4)
-    hipLaunchKernelGGL(block_fused_bf16<4>, dim3((unsigned)mvt_cdiv(M, 128)), dim3(NT), 0, mvt_stream(stream), a);
-  else if (nmb == 2)
+  if (nmb == 2)
     hipLaunchKernelGGL(block_fused_bf16<2>, dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
   else
     hipLaunchKernelGGL(block_fused_bf16<1>, dim3((unsigned)mvt_cdiv(M, 32)), dim3(NT), 0, mvt_stream(stream), a);

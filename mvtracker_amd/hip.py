@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmvtracker_hip.so")
+LIB_PATH = os.environ.get("MVT_LIB") or os.path.join(_HERE, "lib", "libmvtracker_hip.so")  # MVT_LIB: A/B builds of the same ABI
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
