@@ -133,7 +133,10 @@ typedef struct mvt_block_next {
   float* y;                /* [M][ldy] */
   int ldw, N, ldy;
   float eps;
+  long long row_lo, row_hi; /* the projection is evaluated for rows [row_lo, row_hi) only (y is indexed by the global row);
+                               row_hi == 0: every row */
 } mvt_block_next;
+#define MVT_BLOCK_MAX_NEXT 3
 int mvt_block_fused_bf16(float* x, int ldx, const float* att, int ldatt, int Ko, const unsigned short* wo, int ldwo,
                          const float* bo, const unsigned short* w1, int ldw1, const float* b1, const unsigned short* w2,
                          int ldw2, const float* b2, int H, const mvt_block_next* next, int n_next, long long M, int C,

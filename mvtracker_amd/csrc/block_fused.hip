@@ -56,7 +56,7 @@ struct BlockArgs {
   const unsigned short* w2;  // fragment-major bf16 of [C][H]
   const float* b2;
   int ldw1, ldw2, H;
-  mvt_block_next next[2];    // up to two follow-up projections of LayerNorm(x)
+  mvt_block_next next[MVT_BLOCK_MAX_NEXT];    // follow-up projections of LayerNorm(x)
   int n_next;
   long long M;
 };
@@ -284,7 +284,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   };
   ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
   bf16x8 wq[PFQ];  // the weight-fragment queue, chained through the MLP and the follow-up projections
-  const bool tail_next = p.n_next > 0 && wave < (p.next[0].N + 31) / 32;
+  // a projection runs in this workgroup when its row range meets the workgroup's rows (workgroup-uniform)
+  auto active = [&](int q) { return q < p.n_next && m0 < p.next[q].row_hi && m0 + BM > p.next[q].row_lo; };
+  const bool tail_next = active(0) && wave < (p.next[0].N + 31) / 32;
   {
     f32x16 acc2[NMB];
 #pragma unroll
@@ -343,8 +345,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
   bool have = tail_next;  // the queue already holds this wave's first block of the projection
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {  // static indices: a dynamically indexed kernel-argument array would live in scratch
+  for (int q = 0; q < MVT_BLOCK_MAX_NEXT; ++q) {  // static indices: a dynamically indexed kernel-argument array would live in scratch
     if (q >= p.n_next) break;
+    if (!active(q)) continue;  // (have is false here: a chain is only set up towards an active projection)
     const mvt_block_next nx = p.next[q];
     __syncthreads();  // every wave is done reading Xs / Hs
     // the projection's bias goes through LDS (b1s is free after the MLP; N <= 4C): a global load in the epilogue would sit
@@ -354,10 +357,11 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     const int nblocks = (nx.N + 31) / 32;
     auto nrow_of = [&](int nb) { return nx.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
     if (wave < nblocks && !have) fill_wq(wq, nrow_of(wave));
-    // after this wave's last block the queue moves on to its first block of the next projection, if there is one
+    // after this wave's last block the queue moves on to its first block of the next projection, if that one runs here
+    const int qn = q + 1 < MVT_BLOCK_MAX_NEXT ? q + 1 : MVT_BLOCK_MAX_NEXT - 1;
     const unsigned short* chain = nullptr;
-    if (q + 1 < p.n_next && wave < (p.next[q + 1 < 2 ? q + 1 : 1].N + 31) / 32)
-      chain = p.next[q + 1 < 2 ? q + 1 : 1].w + ((long long)wave * (C / 16) * 64 + lane) * 8;
+    if (q + 1 < MVT_BLOCK_MAX_NEXT && active(q + 1) && wave < (p.next[qn].N + 31) / 32)
+      chain = p.next[qn].w + ((long long)wave * (C / 16) * 64 + lane) * 8;
     have = chain != nullptr && wave < nblocks;
     for (int nb = wave; nb < nblocks; nb += 8) {
       f32x16 acc[NMB];
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
         const long long m = m0 + mb * 32 + r;
-        if (m >= p.M) continue;
+        if (m >= p.M || m < nx.row_lo || m >= nx.row_hi) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = nb * 32 + 8 * g + 4 * h;
@@ -423,7 +427,7 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const float* att, int lda
   MVT_REQUIRE(x && w1 && b1 && w2 && b2 && M > 0 && Cc == C && H > 0 && H % 256 == 0 && H <= 4 * C);
   MVT_REQUIRE(ldx % 4 == 0 && ldx >= C);
   MVT_REQUIRE(!att || (wo && bo && Ko == 288 && ldatt % 4 == 0 && ldatt >= Ko));
-  MVT_REQUIRE(n_next >= 0 && n_next <= 2 && (n_next == 0 || next));
+  MVT_REQUIRE(n_next >= 0 && n_next <= MVT_BLOCK_MAX_NEXT && (n_next == 0 || next));
   MVT_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)att % 16 == 0) && ((uintptr_t)wo % 16 == 0) && ((uintptr_t)w1 % 16 == 0) &&
               ((uintptr_t)w2 % 16 == 0));
   BlockArgs a{};
@@ -433,7 +437,9 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const float* att, int lda
     const mvt_block_next& nx = next[q];
     MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
     MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo));
     a.next[q] = nx;
+    if (nx.row_hi == 0) a.next[q].row_hi = M;
   }
   static const char* force = getenv("MVT_BLOCK_NMB");  // tuning override
   const int nmb = force ? atoi(force) : (M >= 4096 ? 2 : 1);  // 64-row workgroups measured 1.6x faster than 128-row ones at M = 12288

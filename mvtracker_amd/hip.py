@@ -158,15 +158,20 @@ def pack_frag_bf16(w, ld, N, K, out):
 class BlockNext(C.Structure):
     """mvt_block_next of include/mvtracker_hip.h."""
     _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("lnw", C.c_void_p), ("lnb", C.c_void_p), ("y", C.c_void_p),
-                ("ldw", C.c_int), ("N", C.c_int), ("ldy", C.c_int), ("eps", C.c_float)]
+                ("ldw", C.c_int), ("N", C.c_int), ("ldy", C.c_int), ("eps", C.c_float), ("row_lo", C.c_longlong),
+                ("row_hi", C.c_longlong)]
+
+
+BLOCK_MAX_NEXT = 3
 
 
 def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw2, b2, H, nexts, M, Cc):
-    """nexts: list of dicts(w, ldw, b, N, lnw, lnb, eps, y, ldy) -- at most two follow-up projections."""
+    """nexts: list of dicts(w, ldw, b, N, lnw, lnb, eps, y, ldy[, rows=(lo, hi)]) -- at most BLOCK_MAX_NEXT follow-up
+    projections; ``rows`` restricts one to a row range (y is always indexed by the global row)."""
     arr = (BlockNext * max(1, len(nexts)))()
     for i, nx in enumerate(nexts):
         arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],
-                           nx["ldy"], nx["eps"])
+                           nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)))
     _call("mvt_block_fused_bf16", _ptr(x), ldx, _ptr(att), ldatt, Ko, _ptr(wo), ldwo, _ptr(bo), _ptr(w1), ldw1, _ptr(b1), _ptr(w2),
           ldw2, _ptr(b2), H, C.cast(arr, C.c_void_p), len(nexts), M, Cc, _stream())
 

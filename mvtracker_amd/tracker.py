@@ -504,9 +504,9 @@ class MVTracker(nn.Module):
         hip.block_fused_bf16(x, h, att, inner, inner, pk[no + "#frag"], inner, pk[no][1], pk[n1 + "#frag"], h, pk[n1][1],
                              pk[n2 + "#frag"], 4 * h, pk[n2][1], 4 * h, nexts, rows, h)
 
-    def _next(self, pk, name, y, ldy, ln=None, eps=1e-6):
+    def _next(self, pk, name, y, ldy, ln=None, eps=1e-6, rows=(0, 0)):
         _, b, n, k = pk[name]
-        d = dict(w=pk[name + "#frag"], ldw=k, b=b, N=n, y=y, ldy=ldy, eps=eps)
+        d = dict(w=pk[name + "#frag"], ldw=k, b=b, N=n, y=y, ldy=ldy, eps=eps, rows=rows)
         if ln is not None:
             d.update(lnw=ln[0], lnb=ln[1])
         return d
@@ -535,10 +535,12 @@ class MVTracker(nn.Module):
             nxt_qkv = f"{u}time_blocks.{i + 1}.attn.qkv"
             # time attention, then the rest of the time block; its epilogue already projects what the space blocks need
             hip.attention(qkv, 3 * inner, S, 1, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, S, 1, att, inner, n + nv, S, S, H, dh)
-            self._fused_block(pk, tb, "attn", pt, Mp, att[:Mp],
-                              [self._next(pk, v2p + ".cross_attn.to_kv", qkv[:Mp, inner:], 3 * inner, pk[v2p + ".norm_context"], 1e-5),
-                               self._next(pk, p2v + ".cross_attn.to_q", qp, inner)])
-            self._fused_block(pk, tb, "attn", vt, Mv, att[Mp:], [self._next(pk, v2p + ".cross_attn.to_q", qkv[Mp:], 3 * inner)])
+            # (one launch over point and virtual rows: same weights, the follow-up projections differ by row range)
+            self._fused_block(pk, tb, "attn", tok, M, att,
+                              [self._next(pk, v2p + ".cross_attn.to_kv", qkv[:, inner:], 3 * inner, pk[v2p + ".norm_context"], 1e-5,
+                                          rows=(0, Mp)),
+                               self._next(pk, p2v + ".cross_attn.to_q", qp, inner, rows=(0, Mp)),
+                               self._next(pk, v2p + ".cross_attn.to_q", qkv, 3 * inner, rows=(Mp, M))])
             # virtual <- point
             space_attn(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, n, H,
                        dh)

@@ -95,7 +95,9 @@ def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw
     for nx in nexts:
         Wn = _unfrag(nx["w"], nx["N"], Cc)
         a = _bf(F.layer_norm(xv, (Cc,), nx.get("lnw"), nx.get("lnb"), nx["eps"]))
-        _v(nx["y"], M, nx["N"], nx["ldy"]).copy_(a @ Wn.t() + nx["b"][:nx["N"]])
+        lo, hi = nx.get("rows", (0, 0))
+        hi = hi or M
+        _v(nx["y"], hi, nx["N"], nx["ldy"])[lo:hi] = (a @ Wn.t() + nx["b"][:nx["N"]])[lo:hi]
 
 
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):

@@ -242,6 +242,48 @@ def test_block_fused_bf16(hip, M, with_att, n_next):
         assert bool((ys[i][:, N:] == 3.0).all())
 
 
+@pytest.mark.parametrize("M,cut", [(13056, 12288), (1000, 333), (200, 0)])
+def test_block_fused_row_ranges(hip, M, cut):
+    """Three follow-up projections restricted to row ranges (one launch over point + virtual rows): rows outside a range
+    keep their old contents, rows inside equal the unrestricted result bit for bit."""
+    g = torch.Generator().manual_seed(M)
+    C, H, Ko = 256, 1024, 288
+    x = torch.randn(M, C, generator=g)
+    att = torch.randn(M, Ko, generator=g)
+
+    def hw(n, k):
+        w = torch.randn(n, k, generator=g) / math.sqrt(k)
+        hi = split_(w)
+        fr = torch.empty((n + 31) // 32 * 32 * k, device=DEV, dtype=torch.int16)
+        hip.pack_frag_bf16(hi, hi.shape[1], n, k, fr)
+        return fr
+
+    split_ = lambda w: split(hip, G(pad_w(w)), False)[0]
+    who, wh1, wh2 = hw(C, Ko), hw(H, C), hw(C, H)
+    bo, b1, b2 = G(torch.randn(C, generator=g)), G(torch.randn(H, generator=g)), G(torch.randn(C, generator=g))
+    Ns = [576, 288, 288]
+    wn = [hw(N, C) for N in Ns]
+    bn = [G(torch.randn(N, generator=g)) for N in Ns]
+    ranges = [(0, cut), (0, cut), (cut, M)] if cut else [(0, M), (0, 0), (5, 70)]
+
+    def run(restrict):
+        xg = G(x)
+        ys = [torch.full((M, N), 7.0, device=DEV) for N in Ns]
+        nexts = [dict(w=wn[i], ldw=C, b=bn[i], N=N, y=ys[i], ldy=N, eps=1e-6, rows=ranges[i] if restrict else (0, 0))
+                 for i, N in enumerate(Ns)]
+        hip.block_fused_bf16(xg, C, G(att), Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, H, b2, H, nexts, M, C)
+        torch.cuda.synchronize()
+        return xg, ys
+
+    xf, yf = run(False)
+    xr, yr = run(True)
+    assert torch.equal(xf, xr)
+    for i, (lo, hi) in enumerate(ranges):
+        hi = hi or M
+        assert torch.equal(yr[i][lo:hi], yf[i][lo:hi])
+        assert bool((yr[i][:lo] == 7.0).all()) and bool((yr[i][hi:] == 7.0).all())
+
+
 @pytest.mark.parametrize("M", [128, 1000, 13056])
 def test_mlp_fused_bf16(hip, M):
     g = torch.Generator().manual_seed(M)
