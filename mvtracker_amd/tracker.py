@@ -519,7 +519,11 @@ class MVTracker(nn.Module):
         M = Mp + Mv
         tok = torch.empty(M, h, device=dev)
         xn = torch.empty(M, h, device=dev)
-        qkv = torch.empty(M, 3 * inner, device=dev)   # time / virtual-self q|k|v; cross attention: q in [:, :inner], k|v in [:, inner:]
+        # q|k|v of the time / virtual-self attention; cross attention: q in [:, :inner], k|v in [:, inner:].  Two buffers,
+        # swapped every layer: the next layer's time q|k|v is projected (by the block epilogues) while this layer's
+        # cross-attention k|v are still being read.
+        qkv = torch.empty(M, 3 * inner, device=dev)
+        qkv_nx = torch.empty(M, 3 * inner, device=dev)
         qp = torch.empty(Mp, inner, device=dev)       # point <- virtual queries (computed right after the time block)
         att = torch.empty(M, inner, device=dev)
         u = "updateformer."
@@ -549,14 +553,13 @@ class MVTracker(nn.Module):
             space_attn(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, nv, H,
                        dh)
             nx = [self._next(pk, p2v + ".cross_attn.to_kv", qkv[Mp:, inner:], 3 * inner, pk[p2v + ".norm_context"], 1e-5)]
-            # (the next time block's q|k|v of the virtual rows would overwrite the k|v just produced: it is projected
-            #  after the point <- virtual attention has consumed them, see below)
+            if not last:  # the virtual rows are final for this layer: project the next layer's time q|k|v right here
+                nx.append(self._next(pk, nxt_qkv, qkv_nx[Mp:], 3 * inner))
             self._fused_block(pk, vs, "attn", vt, Mv, att[Mp:], nx)
             # point <- virtual
             space_attn(qp, inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[:Mp], inner, S, n, nv, H, dh)
-            self._fused_block(pk, p2v, "cross_attn", pt, Mp, att[:Mp], [] if last else [self._next(pk, nxt_qkv, qkv[:Mp], 3 * inner)])
-            if not last:
-                self._ln_lin(pk, nxt_qkv, vt, Mv, qkv[Mp:], 3 * inner, xn[Mp:])
+            self._fused_block(pk, p2v, "cross_attn", pt, Mp, att[:Mp], [] if last else [self._next(pk, nxt_qkv, qkv_nx[:Mp], 3 * inner)])
+            qkv, qkv_nx = qkv_nx, qkv
         od = self.out_dim
         ldh = _round_up(od, 4)
         h1 = torch.zeros(Mp, ldh, device=dev)
