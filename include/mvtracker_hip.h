@@ -89,11 +89,19 @@ int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const uns
  *   in_stats    [n][Cin][2] (mean, rstd) or NULL: the input is read as relu((x - mean) * rstd) (3x3 stride-1 pad-1 only);
  *   out_partial [n][slots][Cout][2] or NULL: per-channel (sum, sum of squares) of the outputs of every 32-pixel block,
  *               slots = mvt_conv2d_stat_slots(...) (0 = not available for this shape); one writer per slot, reduced in a
- *               fixed order by mvt_instnorm_finish_slots -> deterministic. */
+ *               fixed order by mvt_instnorm_finish_slots -> deterministic.
+ *
+ * io_flags: element type of the activation tensors.  In bf16 mode (wt_lo == NULL) the encoder keeps its intermediate
+ * activations in bf16 -- its big layers are HBM-bound, and the MFMA operands are bf16 anyway:
+ *   MVT_IO_IN_BF16  `in` is bf16 [n][H][W][Cin]   (Cin % 32 == 0; the stem always reads fp32)
+ *   MVT_IO_OUT_BF16 `out` is bf16 [n][Ho][Wo][ldo] (rounded to nearest even from the fp32 accumulator; the statistics
+ *                   in out_partial are taken before the rounding) */
+#define MVT_IO_IN_BF16 1
+#define MVT_IO_OUT_BF16 2
 int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad);
-int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
-                    float* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
-                    int act, const float* in_stats, float* out_partial, void* stream);
+int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
+                    void* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
+                    int act, int io_flags, const float* in_stats, float* out_partial, void* stream);
 int mvt_instnorm_finish_slots(const float* partial, int slots, float* mean_rstd, int n, long long HW, int C, void* stream);
 
 /* mvt_gemm_bf16 with LayerNorm (biased variance, eps, optional affine ln_w / ln_b of length K) applied to every A
@@ -154,18 +162,18 @@ int mvt_resize_nearest(const float* in, float* out, long long planes, int Hi, in
  * channels-last x [n][HW][C]:  stats -> mean_rstd [n][C][2]; `partial` is scratch of
  * n*MVT_IN_SLABS*C*2 doubles. */
 #define MVT_IN_SLABS 64
-int mvt_instnorm_stats(const float* x, int ldx, double* partial, float* mean_rstd, int n, long long HW, int C,
-                       void* stream);
+int mvt_instnorm_stats(const void* x, int ldx, double* partial, float* mean_rstd, int n, long long HW, int C,
+                       int io_flags /* MVT_IO_IN_BF16: x is bf16 */, void* stream);
 /* y = relu((x-mean)*rstd)                                  (skip == NULL)
  * y = relu(skip' + relu((x-mean)*rstd)), skip' = skip or (skip-mean_s)*rstd_s when skip_stats
  * is given (ResidualBlock.forward, blocks.py:119-128).  y may alias x. */
-int mvt_instnorm_apply(const float* x, const float* mean_rstd, const float* skip, const float* skip_stats, float* y,
-                       int n, long long HW, int C, void* stream);
+int mvt_instnorm_apply(const void* x, const float* mean_rstd, const void* skip, const float* skip_stats, void* y,
+                       int n, long long HW, int C, int io_flags /* 0, or IN|OUT: x, skip and y are all bf16 */, void* stream);
 
 /* bilinear resize, align_corners=True, of channels-last src [n][Hs][Ws][C] into the channel
  * slice [c_off, c_off+C) of dst [n][Hd][Wd][ldd] (blocks.py:254-280, the 416-channel concat). */
-int mvt_resize_bilinear_ac(const float* src, float* dst, int n, int Hs, int Ws, int C, int Hd, int Wd, int ldd,
-                           int c_off, void* stream);
+int mvt_resize_bilinear_ac(const void* src, void* dst, int n, int Hs, int Ws, int C, int Hd, int Wd, int ldd,
+                           int c_off, int io_flags /* 0, or IN|OUT: src and dst are bf16 */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Frame store construction (reference: init_pointcloud_from_rgbd, model_utils.py:420-482, and

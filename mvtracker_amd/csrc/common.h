@@ -42,6 +42,32 @@ __device__ __forceinline__ float mvt_act(float x, int act) {
   }
 }
 
+// Activation tensors of the encoder are fp32 or, in bf16 mode, bf16 (MVT_IO_* flags).  Element offsets, fp32 values.
+__device__ __forceinline__ unsigned short mvt_bf16_bits(float v) {  // round to nearest even
+  const unsigned u = __float_as_uint(v);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ f32x4 load_act4(const float* base, long long off, int is_bf16) {
+  if (!is_bf16) return *reinterpret_cast<const f32x4*>(base + off);
+  const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+  return (f32x4){__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16),
+                 __uint_as_float(w.y & 0xFFFF0000u)};
+}
+__device__ __forceinline__ void store_act(float* base, long long off, float v, int is_bf16) {
+  if (!is_bf16) base[off] = v;
+  else reinterpret_cast<unsigned short*>(base)[off] = mvt_bf16_bits(v);
+}
+__device__ __forceinline__ void store_act4(float* base, long long off, const f32x4& v, int is_bf16) {
+  if (!is_bf16) {
+    *reinterpret_cast<f32x4*>(base + off) = v;
+  } else {
+    uint2 w;
+    w.x = (unsigned)mvt_bf16_bits(v[0]) | ((unsigned)mvt_bf16_bits(v[1]) << 16);
+    w.y = (unsigned)mvt_bf16_bits(v[2]) | ((unsigned)mvt_bf16_bits(v[3]) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = w;
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -41,7 +41,7 @@ __global__ void resize_nearest_kernel(const float* __restrict__ in, float* __res
 
 // stage 1: block (slab, image) sums channel quads over its pixel slab in fp64
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, int ldx, double* __restrict__ partial,
-                                                               long long HW, int C) {
+                                                               long long HW, int C, int bf) {
   __shared__ double red[256 * 8];
   const int slab = blockIdx.x, img = blockIdx.y;
   const int cq = C / 4;              // channel quads per pixel
@@ -52,9 +52,9 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __re
   const long long p0 = slab * per, p1 = min(HW, p0 + per);
   double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
   if (pl < lanes) {
-    const float* base = x + (long long)img * HW * ldx + q * 4;
+    const long long base = (long long)img * HW * ldx + q * 4;
     for (long long p = p0 + pl; p < p1; p += lanes) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(base + p * ldx);
+      f32x4 v = load_act4(x, base + p * ldx, bf);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         s[e] += (double)v[e];
@@ -135,18 +135,19 @@ __global__ __launch_bounds__(1024) void instnorm_finish_slots_kernel(const float
 }
 
 __global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ st, const float* __restrict__ skip,
-                                      const float* __restrict__ skst, float* __restrict__ y, long long HW, int C, long long total4) {
+                                      const float* __restrict__ skst, float* __restrict__ y, long long HW, int C, long long total4,
+                                      int bf) {
   const int cq = C / 4;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     int q = (int)(i % cq);
     long long img = (i / cq) / HW;
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 v = load_act4(x, i * 4, bf);
     const float* s = st + (img * C + q * 4) * 2;
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[e] - s[e * 2]) * s[e * 2 + 1], 0.0f);
     if (skip) {
-      f32x4 k = *reinterpret_cast<const f32x4*>(skip + i * 4);
+      f32x4 k = load_act4(skip, i * 4, bf);
       if (skst) {
         const float* ks = skst + (img * C + q * 4) * 2;
 #pragma unroll
@@ -155,12 +156,12 @@ __global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* 
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fmaxf(k[e] + o[e], 0.0f);
     }
-    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    store_act4(y, i * 4, o, bf);
   }
 }
 
 __global__ void resize_bilinear_ac_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int Hs, int Ws, int C, int Hd,
-                                          int Wd, int ldd, int c_off) {
+                                          int Wd, int ldd, int c_off, int bf) {
   // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1)
   const float rh = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
   const float rw = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
@@ -177,15 +178,15 @@ __global__ void resize_bilinear_ac_kernel(const float* __restrict__ src, float* 
     int y0 = (int)fy, x0 = (int)fx;
     int yp = y0 < Hs - 1 ? 1 : 0, xp = x0 < Ws - 1 ? 1 : 0;
     float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
-    const float* b = src + ((img * Hs + y0) * (long long)Ws + x0) * C + q * 4;
-    f32x4 a00 = *reinterpret_cast<const f32x4*>(b);
-    f32x4 a01 = *reinterpret_cast<const f32x4*>(b + (long long)xp * C);
-    f32x4 a10 = *reinterpret_cast<const f32x4*>(b + (long long)yp * Ws * C);
-    f32x4 a11 = *reinterpret_cast<const f32x4*>(b + ((long long)yp * Ws + xp) * C);
+    const long long b = ((img * Hs + y0) * (long long)Ws + x0) * C + q * 4;
+    f32x4 a00 = load_act4(src, b, bf);
+    f32x4 a01 = load_act4(src, b + (long long)xp * C, bf);
+    f32x4 a10 = load_act4(src, b + (long long)yp * Ws * C, bf);
+    f32x4 a11 = load_act4(src, b + ((long long)yp * Ws + xp) * C, bf);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = hy * (hx * a00[e] + lx * a01[e]) + ly * (hx * a10[e] + lx * a11[e]);
-    *reinterpret_cast<f32x4*>(dst + pix * ldd + c_off + q * 4) = o;
+    store_act4(dst, pix * ldd + c_off + q * 4, o, bf);
   }
 }
 
@@ -210,11 +211,13 @@ extern "C" int mvt_resize_nearest(const float* in, float* out, long long planes,
   return mvt_launch_status();
 }
 
-extern "C" int mvt_instnorm_stats(const float* x, int ldx, double* partial, float* mean_rstd, int n, long long HW, int C,
-                                  void* stream) {
+extern "C" int mvt_instnorm_stats(const void* x, int ldx, double* partial, float* mean_rstd, int n, long long HW, int C,
+                                  int io_flags, void* stream) {
+  MVT_REQUIRE((io_flags & ~MVT_IO_IN_BF16) == 0);
   MVT_REQUIRE(x && partial && mean_rstd && n > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 256 && ldx >= C && ldx % 4 == 0);
   MVT_REQUIRE(256 % (C / 4) == 0 || C / 4 <= 64);
-  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(MVT_IN_SLABS, n), dim3(256), 0, mvt_stream(stream), x, ldx, partial, HW, C);
+  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(MVT_IN_SLABS, n), dim3(256), 0, mvt_stream(stream), (const float*)x, ldx, partial,
+                     HW, C, io_flags & MVT_IO_IN_BF16 ? 1 : 0);
   long long total = (long long)n * C;
   hipLaunchKernelGGL(instnorm_finish_kernel, dim3((unsigned)mvt_cdiv(total, 256)), dim3(256), 0, mvt_stream(stream), partial,
                      mean_rstd, HW, C, total);
@@ -228,22 +231,25 @@ extern "C" int mvt_instnorm_finish_slots(const float* partial, int slots, float*
   return mvt_launch_status();
 }
 
-extern "C" int mvt_instnorm_apply(const float* x, const float* mean_rstd, const float* skip, const float* skip_stats, float* y,
-                                  int n, long long HW, int C, void* stream) {
+extern "C" int mvt_instnorm_apply(const void* x, const float* mean_rstd, const void* skip, const float* skip_stats, void* y,
+                                  int n, long long HW, int C, int io_flags, void* stream) {
   MVT_REQUIRE(x && mean_rstd && y && n > 0 && HW > 0 && C > 0 && C % 4 == 0);
+  const int both = MVT_IO_IN_BF16 | MVT_IO_OUT_BF16;
+  MVT_REQUIRE(io_flags == 0 || io_flags == both);  // x, skip and y share one element type
   MVT_REQUIRE(skip || !skip_stats);
   long long total4 = (long long)n * HW * (C / 4);
-  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, mvt_stream(stream), x, mean_rstd, skip, skip_stats,
-                     y, HW, C, total4);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, mvt_stream(stream), (const float*)x, mean_rstd,
+                     (const float*)skip, skip_stats, (float*)y, HW, C, total4, io_flags ? 1 : 0);
   return mvt_launch_status();
 }
 
-extern "C" int mvt_resize_bilinear_ac(const float* src, float* dst, int n, int Hs, int Ws, int C, int Hd, int Wd, int ldd,
-                                      int c_off, void* stream) {
+extern "C" int mvt_resize_bilinear_ac(const void* src, void* dst, int n, int Hs, int Ws, int C, int Hd, int Wd, int ldd,
+                                      int c_off, int io_flags, void* stream) {
   MVT_REQUIRE(src && dst && n > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && C % 4 == 0);
+  MVT_REQUIRE(io_flags == 0 || io_flags == (MVT_IO_IN_BF16 | MVT_IO_OUT_BF16));
   MVT_REQUIRE(ldd % 4 == 0 && c_off % 4 == 0 && c_off >= 0 && c_off + C <= ldd);
   long long total = (long long)n * Hd * Wd * (C / 4);
-  hipLaunchKernelGGL(resize_bilinear_ac_kernel, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), src, dst, n, Hs, Ws, C, Hd,
-                     Wd, ldd, c_off);
+  hipLaunchKernelGGL(resize_bilinear_ac_kernel, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), (const float*)src, (float*)dst,
+                     n, Hs, Ws, C, Hd, Wd, ldd, c_off, io_flags ? 1 : 0);
   return mvt_launch_status();
 }

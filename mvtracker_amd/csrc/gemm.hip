@@ -37,6 +37,7 @@ struct GemmArgs {
   const float* in_stats;
   float* out_part;
   int slots;
+  int a_bf16, c_bf16;  // bf16 conv kernels: activations read / written as bf16 instead of fp32 (conv modes only)
   int ln;
   float ln_eps;
   const float* ln_w;
@@ -253,11 +254,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
   const int n0 = tile_n * BN;
 
   const float* a_ptr[AF];
+  long long a_img[AF];  // conv modes: element offset of the row's image (the tensor may be bf16)
   unsigned a_hw[AF];
 #pragma unroll
   for (int i = 0; i < AF; ++i) {
     long long m = m0 + rbase + 16 * i;
     bool ok = m < p.M;
+    a_img[i] = 0;
     if (p.mode == 0) {
       a_ptr[i] = p.A + (ok ? m : 0) * (long long)p.lda + c4 * 4;
       a_hw[i] = ok ? 1 : 0;
@@ -268,7 +271,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
       int oh = rem / p.Wo, ow = rem - oh * p.Wo;
       int ih0 = ok ? oh * p.stride - p.pad : -20000;
       int iw0 = ow * p.stride - p.pad;
-      a_ptr[i] = p.A + img * (long long)p.H * p.Wd * p.Cin;
+      a_img[i] = img * (long long)p.H * p.Wd * p.Cin;
+      a_ptr[i] = p.A + a_img[i];
       a_hw[i] = ((unsigned)(ih0 + 32000) << 16) | (unsigned)(iw0 + 64);
     }
   }
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
         int iw = (int)(a_hw[i] & 0xFFFFu) - 64 + kw;
         ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
-          ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((long long)ih * p.Wd + iw) * p.Cin + c);
+          ra[i] = load_act4(p.A, a_img[i] + ((long long)ih * p.Wd + iw) * p.Cin + c, p.a_bf16);
       }
     } else {
       const int kh = k >> 5, kw = (k & 31) >> 2;
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16(GemmArgs p) {
         if (nok && m < p.M) {
           float v = mvt_act(acc[i][j][e] + bv, p.act);
           if (p.R) v += p.R[m * p.ldr + n];
-          p.C[m * p.ldc + n] = v;
+          store_act(p.C, m * p.ldc + n, v, p.c_bf16);
           s1 += v;
           s2 = fmaf(v, v, s2);
         }
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16(GemmArgs p) {
   const int ty = b % tiles_y;
   const long long img = b / tiles_y;
   const int y0 = ty * HT, x0 = tx * HW_, n0 = tn * BN;
-  const float* in = p.A + img * (long long)p.H * p.Wd * p.Cin;
+  const long long in_off = img * (long long)p.H * p.Wd * p.Cin;  // element offset (fp32 or bf16 input)
 
   // patch loader state: pixel / quad of each of this thread's float4
   long long poff[NPF];
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       rp[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (pok[i]) rp[i] = *reinterpret_cast<const f32x4*>(in + poff[i] + c0);
+      if (pok[i]) rp[i] = load_act4(p.A, in_off + poff[i] + c0, p.a_bf16);
     }
   };
   f32x4 st_m = (f32x4){0.f, 0.f, 0.f, 0.f}, st_r = (f32x4){1.f, 1.f, 1.f, 1.f};  // stats of this thread's channel quad
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16(GemmArgs p) {
     }
   }
 
-  float* outb = p.C + img * (long long)p.Ho * p.Wo * p.ldc;
+  const long long out_off = img * (long long)p.Ho * p.Wo * p.ldc;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + r;
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16(GemmArgs p) {
         const int y = y0 + m / HW_, x = x0 + m % HW_;
         if (nok && y < p.Ho && x < p.Wo) {
           const float v = mvt_act(acc[i][j][e] + bv, p.act);
-          outb[((long long)y * p.Wo + x) * p.ldc + n] = v;
+          store_act(p.C, out_off + ((long long)y * p.Wo + x) * p.ldc + n, v, p.c_bf16);
           s1 += v;
           s2 = fmaf(v, v, s2);
         }
@@ -831,9 +835,9 @@ extern "C" int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int 
   return ((long long)Ho * Wo) % 256 == 0 ? Ho * Wo / 32 : 0;  // im2col tiles are <= 256 rows: they must not straddle images
 }
 
-extern "C" int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
-                               float* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
-                               int act, const float* in_stats, float* out_partial, void* stream) {
+extern "C" int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
+                               void* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
+                               int act, int io_flags, const float* in_stats, float* out_partial, void* stream) {
   MVT_REQUIRE(in && wt_hi && out && n > 0 && H > 0 && W > 0 && Cout > 0);
   MVT_REQUIRE(KH >= 1 && KH <= 7 && KW >= 1 && KW <= 7 && stride >= 1 && stride <= 2 && pad >= 0 && pad <= 3);
   MVT_REQUIRE(H < 16384 && W < 16384 && ldo >= Cout && act >= 0 && act <= 3);
@@ -845,7 +849,7 @@ extern "C" int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, con
   const long long M = (long long)n * Ho * Wo;
   MVT_REQUIRE(M < (1LL << 31));
   GemmArgs a{};
-  a.A = in; a.Whi = wt_hi; a.Wlo = wt_lo; a.bias = bias; a.R = nullptr; a.C = out;
+  a.A = (const float*)in; a.Whi = wt_hi; a.Wlo = wt_lo; a.bias = bias; a.R = nullptr; a.C = (float*)out;
   a.M = (int)M; a.N = Cout; a.ldc = ldo; a.ldr = 0; a.act = act;
   a.H = H; a.Wd = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
   if (Cin == 4) {
@@ -860,6 +864,10 @@ extern "C" int mvt_conv2d_bf16(const float* in, const unsigned short* wt_hi, con
   MVT_REQUIRE(!in_stats || (halo && ((uintptr_t)in_stats % 16 == 0)));  // normalise-on-load exists in the halo kernel only
   a.in_stats = in_stats;
   a.out_part = out_partial;
+  a.a_bf16 = io_flags & MVT_IO_IN_BF16 ? 1 : 0;
+  a.c_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
+  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16)) == 0 && (!io_flags || !wt_lo));  // bf16 tensors: bf16 mode only
+  MVT_REQUIRE(!a.a_bf16 || (Cin % 32 == 0 && (uintptr_t)in % 8 == 0));                          // (the stem reads fp32 RGB)
   a.slots = mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad);
   MVT_REQUIRE(!out_partial || a.slots > 0);
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0 && (long long)n * mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4 < (1LL << 31))

@@ -32,7 +32,7 @@ SIGNATURES = {
     "mvt_split_bf16": [P, P, P, LL, P],
     "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_conv2d_stat_slots": [I, I, I, I, I, I, I],
-    "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P],
+    "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P],
     "mvt_instnorm_finish_slots": [P, I, P, I, LL, I, P],
     "mvt_ln_gemm_bf16": [P, I, P, P, F, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_pack_frag_bf16": [P, I, I, I, P, P],
@@ -40,9 +40,9 @@ SIGNATURES = {
     "mvt_mlp_fused_bf16": [P, I, P, I, P, P, I, P, LL, I, I, F, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
-    "mvt_instnorm_stats": [P, I, P, P, I, LL, I, P],
-    "mvt_instnorm_apply": [P, P, P, P, P, I, LL, I, P],
-    "mvt_resize_bilinear_ac": [P, P, I, I, I, I, I, I, I, I, P],
+    "mvt_instnorm_stats": [P, I, P, P, I, LL, I, I, P],
+    "mvt_instnorm_apply": [P, P, P, P, P, I, LL, I, I, P],
+    "mvt_resize_bilinear_ac": [P, P, I, I, I, I, I, I, I, I, I, P],
     "mvt_invert_cameras": [P, P, P, P, I, P],
     "mvt_depth_subsample": [P, P, I, I, I, I, I, P],
     "mvt_avgpool2": [P, P, LL, I, I, I, P],
@@ -101,6 +101,17 @@ def _call(name, *args):
         raise HipError(f"{name} failed with code {rc}" + (" (arguments rejected)" if rc == 1 else " (HIP launch error)"))
 
 
+IO_IN_BF16, IO_OUT_BF16 = 1, 2
+
+
+def _io(t_in, t_out=None):
+    """MVT_IO_* flags from the element types of the activation tensors (fp32 or bf16)."""
+    for t in (t_in, t_out):
+        assert t is None or t.dtype in (torch.float32, torch.bfloat16), t.dtype
+    return (IO_IN_BF16 if t_in is not None and t_in.dtype == torch.bfloat16 else 0) | \
+           (IO_OUT_BF16 if t_out is not None and t_out.dtype == torch.bfloat16 else 0)
+
+
 def _f32c(t):
     assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
     return t
@@ -139,7 +150,7 @@ def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad) -> int:
 def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE, in_stats=None,
                 out_partial=None):
     _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
-          ldo, act, _ptr(in_stats), _ptr(out_partial), _stream())
+          ldo, act, _io(x, out), _ptr(in_stats), _ptr(out_partial), _stream())
 
 
 def instnorm_finish_slots(partial, slots, mean_rstd, n, HW, Cc):
@@ -189,15 +200,17 @@ def resize_nearest(x, out, planes, Hi, Wi, Ho, Wo):
 
 
 def instnorm_stats(x, ldx, partial, mean_rstd, n, HW, Cc):
-    _call("mvt_instnorm_stats", _ptr(x), ldx, _ptr(partial), _ptr(mean_rstd), n, HW, Cc, _stream())
+    _call("mvt_instnorm_stats", _ptr(x), ldx, _ptr(partial), _ptr(mean_rstd), n, HW, Cc, _io(x), _stream())
 
 
 def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc):
-    _call("mvt_instnorm_apply", _ptr(x), _ptr(mean_rstd), _ptr(skip), _ptr(skip_stats), _ptr(y), n, HW, Cc, _stream())
+    assert y.dtype == x.dtype and (skip is None or skip.dtype == x.dtype)
+    _call("mvt_instnorm_apply", _ptr(x), _ptr(mean_rstd), _ptr(skip), _ptr(skip_stats), _ptr(y), n, HW, Cc, _io(x, y), _stream())
 
 
 def resize_bilinear_ac(src, dst, n, Hs, Ws, Cc, Hd, Wd, ldd, c_off):
-    _call("mvt_resize_bilinear_ac", _ptr(src), _ptr(dst), n, Hs, Ws, Cc, Hd, Wd, ldd, c_off, _stream())
+    assert src.dtype == dst.dtype
+    _call("mvt_resize_bilinear_ac", _ptr(src), _ptr(dst), n, Hs, Ws, Cc, Hd, Wd, ldd, c_off, _io(src, dst), _stream())
 
 
 def invert_cameras(intrs, extrs, kinv, einv, n):

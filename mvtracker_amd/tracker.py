@@ -109,6 +109,7 @@ class MVTracker(nn.Module):
         self.mfma_attention = True
         self.overlap_encoder = os.environ.get("MVT_OVERLAP", "1") != "0"  # encode later frames on a second stream
         self._side = {}
+        self.bf16_activations = os.environ.get("MVT_BF16_ACT", "0") != "0"  # bf16 mode: encoder activations stored as bf16
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
         d = self.updateformer_input_dim
@@ -275,7 +276,7 @@ class MVTracker(nn.Module):
         Ho = (H + 2 * pad - k) // stride + 1
         Wo = (W + 2 * pad - k) // stride + 1
         if out is None:
-            out = torch.empty(n, Ho, Wo, cout, device=x.device)
+            out = torch.empty(n, Ho, Wo, cout, device=x.device, dtype=self._act_dtype(pk))
             ldo = cout
         st = None
         if isinstance(wt, tuple):
@@ -291,6 +292,10 @@ class MVTracker(nn.Module):
         if stats and st is None:
             st = self._inorm(out, n, Ho * Wo, cout, apply=False)
         return (out, Ho, Wo, st) if stats else (out, Ho, Wo)
+
+    def _act_dtype(self, pk):
+        """Element type of the encoder's intermediate activations: bf16 in bf16 mode (HBM-bound layers, bf16 MFMA operands)."""
+        return torch.bfloat16 if (self.bf16_activations and self.precision == "bf16") else torch.float32
 
     def _inorm(self, x, n, HW, C, skip=None, skip_stats=None, apply=True, st=None):
         if st is None:
@@ -321,7 +326,7 @@ class MVTracker(nn.Module):
         hs, ws = H // self.stride, W // self.stride
         x, h, w, st = self._conv(pk, "fnet.conv1", x4, n, H, W, 4, 64, 7, 2, 3, stats=True)
         self._inorm(x, n, h * w, 64, st=st)
-        cat = torch.empty(n, hs, ws, 416, device=x4.device)
+        cat = torch.empty(n, hs, ws, 416, device=x4.device, dtype=self._act_dtype(pk))
         cin, off = 64, 0
         for li, (cout, stride) in enumerate(((64, 1), (96, 2), (128, 2), (128, 2)), start=1):
             x, h, w = self._res_block(pk, f"fnet.layer{li}.0", x, n, h, w, cin, cout, stride)

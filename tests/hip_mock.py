@@ -122,13 +122,13 @@ def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, 
     xin = x
     if in_stats is not None:
         st = in_stats.reshape(n, 1, Cin, 2)
-        xin = F.relu((torch.as_strided(x, (n, H * W, Cin), (H * W * Cin, Cin, 1)) - st[..., 0]) * st[..., 1]).contiguous()
-    xin = xin if wt_lo is not None else _bf(xin)
+        xin = F.relu((torch.as_strided(x, (n, H * W, Cin), (H * W * Cin, Cin, 1)).float() - st[..., 0]) * st[..., 1]).contiguous()
+    xin = xin if wt_lo is not None else _bf(xin.float())
     conv2d(xin, w, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act)
     if out_partial is not None:  # the mock puts the whole image sum into slot 0
         slots = conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad)
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-        y = torch.as_strided(out, (n, Ho * Wo, Cout), (Ho * Wo * ldo, ldo, 1))
+        y = torch.as_strided(out, (n, Ho * Wo, Cout), (Ho * Wo * ldo, ldo, 1)).float()
         pp = out_partial.reshape(-1)[:n * slots * Cout * 2].reshape(n, slots, Cout, 2)
         pp.zero_()
         pp[:, 0, :, 0] = y.sum(1)
@@ -145,7 +145,7 @@ def instnorm_finish_slots(partial, slots, mean_rstd, n, HW, Cc):
 
 
 def conv2d(x, wt, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0):
-    xi = torch.as_strided(x, (n, H, W, Cin), (H * W * Cin, W * Cin, Cin, 1)).permute(0, 3, 1, 2)
+    xi = torch.as_strided(x, (n, H, W, Cin), (H * W * Cin, W * Cin, Cin, 1)).permute(0, 3, 1, 2).float()
     ld = ((KH * 32 if Cin == 4 else KH * KW * Cin) + 63) // 64 * 64
     if Cin == 4:
         w = torch.as_strided(wt, (Cout, KH, 8, 4), (ld, 32, 4, 1))[:, :, :KW, :].permute(0, 3, 1, 2)
@@ -178,11 +178,11 @@ def instnorm_stats(x, ldx, partial, mean_rstd, n, HW, Cc):
 
 
 def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc):
-    xv = torch.as_strided(x, (n, HW, Cc), (HW * Cc, Cc, 1))
+    xv = torch.as_strided(x, (n, HW, Cc), (HW * Cc, Cc, 1)).float()
     st = torch.as_strided(mean_rstd, (n, 1, Cc, 2), (Cc * 2, 0, 2, 1))
     o = F.relu((xv - st[..., 0]) * st[..., 1])
     if skip is not None:
-        k = torch.as_strided(skip, (n, HW, Cc), (HW * Cc, Cc, 1))
+        k = torch.as_strided(skip, (n, HW, Cc), (HW * Cc, Cc, 1)).float()
         if skip_stats is not None:
             ks = torch.as_strided(skip_stats, (n, 1, Cc, 2), (Cc * 2, 0, 2, 1))
             k = (k - ks[..., 0]) * ks[..., 1]
@@ -191,7 +191,7 @@ def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc):
 
 
 def resize_bilinear_ac(src, dst, n, Hs, Ws, Cc, Hd, Wd, ldd, c_off):
-    s = torch.as_strided(src, (n, Hs, Ws, Cc), (Hs * Ws * Cc, Ws * Cc, Cc, 1)).permute(0, 3, 1, 2)
+    s = torch.as_strided(src, (n, Hs, Ws, Cc), (Hs * Ws * Cc, Ws * Cc, Cc, 1)).permute(0, 3, 1, 2).float()
     y = F.interpolate(s, (Hd, Wd), mode="bilinear", align_corners=True)
     torch.as_strided(dst, (n, Hd, Wd, Cc), (Hd * Wd * ldd, Wd * ldd, ldd, 1), dst.storage_offset() + c_off).copy_(y.permute(0, 2, 3, 1))
 

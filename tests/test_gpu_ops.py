@@ -167,6 +167,77 @@ def test_conv2d_fused_instnorm(hip, cfg, prec):
     assert ((st[..., 1].double() * torch.sqrt(var + 1e-5)) - 1).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("cfg", [(2, 24, 40, 64, 96, 3, 1, 1), (2, 32, 64, 64, 96, 3, 2, 1), (2, 32, 32, 96, 128, 1, 2, 0),
+                                 (1, 64, 64, 3, 64, 7, 2, 3), (1, 16, 24, 416, 256, 3, 1, 1)])
+def test_conv2d_bf16_activation_tensors(hip, cfg):
+    """bf16 activation tensors (bf16 mode): same arithmetic as fp32 tensors holding the bf16 values, output rounded
+    to nearest even, statistics untouched."""
+    n, H, W, Cin, Cout, k, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + 3)
+    x = (torch.randn(n, H, W, Cin, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    w = torch.randn(Cout, k, k, Cin, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    stem = Cin == 3
+    if stem:  # the stem reads fp32 RGB, only its output is bf16
+        x4 = torch.zeros(n, H, W, 4)
+        x4[..., :3] = x.float()
+        wt = torch.zeros(Cout, 7, 8, 4)
+        wt[:, :, :7, :3] = w
+        xin_f, w, cin = G(x4), wt.reshape(Cout, 224), 4
+        xin_b = xin_f
+    else:
+        cin = Cin
+        xin_f, xin_b = G(x.float()), G(x)
+    hi, _ = split(hip, G(pad_w(w.reshape(Cout, -1))), False)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    halo = k == 3 and s == 1
+    slots = hip.conv2d_stat_slots(H, W, cin, k, k, s, p)
+    in_st = None
+    if halo:
+        in_st = G(torch.stack([torch.randn(n, cin, generator=g) * 0.2, torch.rand(n, cin, generator=g) + 0.5], -1))
+    outs, parts = [], []
+    for xin, dt in ((xin_f, torch.float32), (xin_b, torch.bfloat16)):
+        out = torch.empty(n, Ho, Wo, Cout, device=DEV, dtype=dt)
+        part = torch.full((n * max(slots, 1) * Cout * 2,), float("nan"), device=DEV)
+        hip.conv2d_bf16(xin, hi, None, G(b), out, n, H, W, cin, Cout, k, k, s, p, Cout, in_stats=in_st, out_partial=part if slots else None)
+        outs.append(out)
+        parts.append(part)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].to(torch.bfloat16), outs[1])
+    if slots:
+        assert torch.equal(parts[0], parts[1])
+
+
+def test_encoder_elementwise_bf16_tensors(hip):
+    g = torch.Generator().manual_seed(77)
+    n, Hh, Ww, C = 2, 12, 20, 96
+    x = (torch.randn(n, Hh * Ww, C, generator=g) * 2).to(torch.bfloat16)
+    sk = torch.randn(n, Hh * Ww, C, generator=g).to(torch.bfloat16)
+    st = G(torch.stack([torch.randn(n, C, generator=g) * 0.2, torch.rand(n, C, generator=g) + 0.5], -1))
+    sst = G(torch.stack([torch.randn(n, C, generator=g) * 0.2, torch.rand(n, C, generator=g) + 0.5], -1))
+    for skip, skst in ((None, None), (sk, None), (sk, sst)):
+        yf = torch.empty(n, Hh * Ww, C, device=DEV)
+        yb = torch.empty(n, Hh * Ww, C, device=DEV, dtype=torch.bfloat16)
+        hip.instnorm_apply(G(x.float()), st, None if skip is None else G(skip.float()), skst, yf, n, Hh * Ww, C)
+        hip.instnorm_apply(G(x), st, None if skip is None else G(skip), skst, yb, n, Hh * Ww, C)
+        torch.cuda.synchronize()
+        assert torch.equal(yf.to(torch.bfloat16), yb)
+    # statistics of a bf16 tensor
+    part = torch.empty(n * hip.IN_SLABS * C * 2, device=DEV, dtype=torch.float64)
+    s1, s2 = torch.empty(n, C, 2, device=DEV), torch.empty(n, C, 2, device=DEV)
+    hip.instnorm_stats(G(x.float()), C, part, s1, n, Hh * Ww, C)
+    hip.instnorm_stats(G(x), C, part, s2, n, Hh * Ww, C)
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s2)
+    # resize into a channel slice
+    df = torch.zeros(n, 24, 40, 128, device=DEV)
+    db = torch.zeros(n, 24, 40, 128, device=DEV, dtype=torch.bfloat16)
+    hip.resize_bilinear_ac(G(x.float()), df, n, Hh, Ww, C, 24, 40, 128, 32)
+    hip.resize_bilinear_ac(G(x), db, n, Hh, Ww, C, 24, 40, 128, 32)
+    torch.cuda.synchronize()
+    assert torch.equal(df.to(torch.bfloat16), db)
+
+
 def test_split_bf16(hip):
     x = torch.randn(4096) * 3
     hi = torch.empty(4096, device=DEV, dtype=torch.int16)
