@@ -88,7 +88,8 @@ int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const uns
  * the two convs of a ResidualBlock, blocks.py:119-122):
  *   in_stats    [n][Cin][2] (mean, rstd) or NULL: the input is read as relu((x - mean) * rstd) (3x3 stride-1 pad-1 only);
  *   out_partial [n][slots][Cout][2] or NULL: per-channel (sum, sum of squares) of the outputs of every 32-pixel block,
- *               slots = mvt_conv2d_stat_slots(...) (0 = not available for this shape); one writer per slot, reduced in a
+ *               slots = mvt_conv2d_stat_slots(...) (0 = not available for this shape; the 3x3 kernels of the two
+ *               precisions cut the image differently); one writer per slot, reduced in a
  *               fixed order by mvt_instnorm_finish_slots -> deterministic.
  *
  * io_flags: element type of the activation tensors.  In bf16 mode (wt_lo == NULL) the encoder keeps its intermediate
@@ -98,7 +99,7 @@ int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const uns
  *                   in out_partial are taken before the rounding) */
 #define MVT_IO_IN_BF16 1
 #define MVT_IO_OUT_BF16 2
-int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad);
+int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad, int split /* wt_lo != NULL */);
 int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
                     void* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
                     int act, int io_flags, const float* in_stats, float* out_partial, void* stream);

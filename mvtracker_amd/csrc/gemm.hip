@@ -828,10 +828,15 @@ extern "C" int mvt_gemm_bf16(const float* A, int lda, const unsigned short* Whi,
   return Wlo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));
 }
 
-extern "C" int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad) {
+int mvt_detail_conv_rows_slots(int H, int W);
+int mvt_detail_conv3x3_rows(const void* in, const unsigned short* w, int ldw, const float* bias, void* out, int n, int H, int W, int Cin,
+                            int Cout, int ldo, int act, int io_flags, const float* in_stats, float* out_partial, hipStream_t stream);
+
+extern "C" int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad, int split) {
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
-  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0) return (int)(mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4);
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0)
+    return split ? (int)(mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4) : mvt_detail_conv_rows_slots(Ho, Wo);
   return ((long long)Ho * Wo) % 256 == 0 ? Ho * Wo / 32 : 0;  // im2col tiles are <= 256 rows: they must not straddle images
 }
 
@@ -868,8 +873,11 @@ extern "C" int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, cons
   a.c_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
   MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16)) == 0 && (!io_flags || !wt_lo));  // bf16 tensors: bf16 mode only
   MVT_REQUIRE(!a.a_bf16 || (Cin % 32 == 0 && (uintptr_t)in % 8 == 0));                          // (the stem reads fp32 RGB)
-  a.slots = mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad);
+  a.slots = mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, wt_lo != nullptr);
   MVT_REQUIRE(!out_partial || a.slots > 0);
+  if (halo && !wt_lo && act == MVT_ACT_NONE)
+    return mvt_detail_conv3x3_rows(in, wt_hi, a.ldw, bias, out, n, H, W, Cin, Cout, ldo, act, io_flags, in_stats, out_partial,
+                                   mvt_stream(stream));
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0 && (long long)n * mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4 < (1LL << 31))
     return wt_lo ? launch_conv3x3_halo<true>(a, n, mvt_stream(stream)) : launch_conv3x3_halo<false>(a, n, mvt_stream(stream));
   return wt_lo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));

@@ -31,7 +31,7 @@ SIGNATURES = {
     "mvt_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "mvt_split_bf16": [P, P, P, LL, P],
     "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, P],
-    "mvt_conv2d_stat_slots": [I, I, I, I, I, I, I],
+    "mvt_conv2d_stat_slots": [I, I, I, I, I, I, I, I],
     "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P],
     "mvt_instnorm_finish_slots": [P, I, P, I, LL, I, P],
     "mvt_ln_gemm_bf16": [P, I, P, P, F, P, P, I, P, P, I, P, I, I, I, I, I, P],
@@ -143,8 +143,9 @@ def gemm_bf16(A, lda, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NON
           _stream())
 
 
-def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad) -> int:
-    return _lib.mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad)
+def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False) -> int:
+    """split: the weights carry a bf16 lo part (bf16x3 mode) -- the two 3x3 kernels cut the image differently."""
+    return _lib.mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, int(split))
 
 
 def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE, in_stats=None,

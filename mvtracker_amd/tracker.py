@@ -109,7 +109,7 @@ class MVTracker(nn.Module):
         self.mfma_attention = True
         self.overlap_encoder = os.environ.get("MVT_OVERLAP", "1") != "0"  # encode later frames on a second stream
         self._side = {}
-        self.bf16_activations = os.environ.get("MVT_BF16_ACT", "0") != "0"  # bf16 mode: encoder activations stored as bf16
+        self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
         d = self.updateformer_input_dim
@@ -280,7 +280,7 @@ class MVTracker(nn.Module):
             ldo = cout
         st = None
         if isinstance(wt, tuple):
-            slots = hip.conv2d_stat_slots(H, W, cin, k, k, stride, pad) if (stats and self.fuse_norm) else 0
+            slots = hip.conv2d_stat_slots(H, W, cin, k, k, stride, pad, wt[1] is not None) if (stats and self.fuse_norm) else 0
             part = torch.empty(n * slots * cout * 2, device=x.device) if slots else None
             hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo, in_stats=in_stats, out_partial=part)
             if slots:

@@ -108,10 +108,10 @@ def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
     xv += _bf(hdn) @ W2.t() + b2[:Cc]
 
 
-def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad):
+def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False):
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     if KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cin % 32 == 0:
-        return ((Ho + 7) // 8) * ((Wo + 15) // 16) * 4
+        return ((Ho + 7) // 8) * ((Wo + 15) // 16) * 4 if split else Ho * ((Wo + 31) // 32)
     return Ho * Wo // 32 if (Ho * Wo) % 256 == 0 else 0
 
 
@@ -126,7 +126,7 @@ def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, 
     xin = xin if wt_lo is not None else _bf(xin.float())
     conv2d(xin, w, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act)
     if out_partial is not None:  # the mock puts the whole image sum into slot 0
-        slots = conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad)
+        slots = conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, wt_lo is not None)
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         y = torch.as_strided(out, (n, Ho * Wo, Cout), (Ho * Wo * ldo, ldo, 1)).float()
         pp = out_partial.reshape(-1)[:n * slots * Cout * 2].reshape(n, slots, Cout, 2)

@@ -140,8 +140,8 @@ def test_conv2d_fused_instnorm(hip, cfg, prec):
     hi, lo = split(hip, G(pad_w(w.reshape(Cout, -1))), prec == "bf16x3")
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     halo = k == 3 and s == 1
-    slots = hip.conv2d_stat_slots(H, W, cin, k, k, s, p)
-    assert slots == (((Ho + 7) // 8) * ((Wo + 15) // 16) * 4 if halo else Ho * Wo // 32)
+    slots = hip.conv2d_stat_slots(H, W, cin, k, k, s, p, prec == "bf16x3")
+    assert slots == ((((Ho + 7) // 8) * ((Wo + 15) // 16) * 4 if prec == "bf16x3" else Ho * ((Wo + 31) // 32)) if halo else Ho * Wo // 32)
     xin = G(x)
     in_st = None
     if halo:  # normalise-on-load against an explicit normalise pass
@@ -191,7 +191,7 @@ def test_conv2d_bf16_activation_tensors(hip, cfg):
     hi, _ = split(hip, G(pad_w(w.reshape(Cout, -1))), False)
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     halo = k == 3 and s == 1
-    slots = hip.conv2d_stat_slots(H, W, cin, k, k, s, p)
+    slots = hip.conv2d_stat_slots(H, W, cin, k, k, s, p, False)
     in_st = None
     if halo:
         in_st = G(torch.stack([torch.randn(n, cin, generator=g) * 0.2, torch.rand(n, cin, generator=g) + 0.5], -1))

@@ -26,7 +26,7 @@ x = torch.randn(n, H, W, Cin, device=dev).to(dt)
 Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 out = torch.empty(n, Ho, Wo, Cout, device=dev, dtype=dt)
 b = torch.randn(Cout, device=dev)
-slots = hip.conv2d_stat_slots(H, W, Cin, k, k, s, p)
+slots = hip.conv2d_stat_slots(H, W, Cin, k, k, s, p, False)
 part = torch.empty(n * max(slots, 1) * Cout * 2, device=dev)
 st = torch.rand(n, Cin, 2, device=dev) + 0.5
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
