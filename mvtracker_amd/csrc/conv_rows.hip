@@ -34,50 +34,64 @@ struct RowsArgs {
   int H, W, Cin, Cout, ldw, ldo, slots, in_bf16, out_bf16;
 };
 
-constexpr int TR = 8;            // output rows per workgroup
+constexpr int TR = 8;            // output rows per workgroup (stem and the stride-1 3x3 kernels)
 constexpr int TC = 32;           // output columns per workgroup
-constexpr int PR = TR + 2, PC = TC + 2;
-constexpr int NPIX = PR * PC;    // 340 patch pixels
 constexpr int CK = 32;           // channels per chunk
 constexpr int LDP = CK + 8;      // bf16 per pixel / weight-row slot (80 B)
 constexpr int MAXC = 512;        // input channels the in-kernel normalisation supports
 
-template <int TM, int TN, int WM, int WN, bool INB>
-__global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
-  static_assert(WM * WN == 4 && WM * TM == TR, "four waves cover the 8 x 32 pixel tile");
-  constexpr int BN = WN * TN * 32;
-  constexpr int NPF = (NPIX * 8 + 255) / 256;   // fp32 input: 16-B pieces (4 channels) per thread per chunk
-  constexpr int NPH = (NPIX * 4 + 255) / 256;   // bf16 input: 16-B pieces (8 channels)
-  constexpr int NWF = (3 * BN * 4 + 255) / 256; // 16-B weight pieces per thread per stage (3 taps x BN rows x 64 B)
-  __shared__ __attribute__((aligned(16))) unsigned short Ps[NPIX * LDP];
-  __shared__ __attribute__((aligned(16))) unsigned short Ws[3 * BN * LDP];
+// Geometry of one workgroup: TM row blocks per wave, four waves stacked in y, kernel size KS (1 or 3), stride S (1 or 2).
+// The patch is stored row by row in 80-B pixel slots.  For the stride-2 3x3 kernel a patch row holds its even columns
+// first and its odd columns after them, so that the pixels 2r + kw of tap kw are consecutive slots again.
+template <int TM, int KS, int S> struct Geo {
+  static constexpr int ROWS = 4 * TM;                                  // output rows
+  static constexpr int PR = KS == 1 ? ROWS : S * (ROWS - 1) + 3;       // patch rows
+  static constexpr int PC = KS == 1 ? TC : S * (TC - 1) + 3;           // patch columns
+  static constexpr int HALF = (PC + 1) / 2;                            // even columns of a split row
+  static constexpr bool SPLITROW = KS == 3 && S == 2;
+  static constexpr int RS = SPLITROW ? 2 * HALF : PC;                  // slots per patch row
+  static constexpr int NSLOT = PR * RS;
+  static constexpr int PAD = KS == 3 ? 1 : 0;
+  static constexpr int PSTEP = KS == 1 ? S : 1;                        // input pixels per patch pixel (1x1: only the sampled ones)
+  __host__ __device__ static constexpr int tap_col(int kw) { return SPLITROW ? (kw & 1) * HALF + (kw >> 1) : kw; }
+  __host__ __device__ static constexpr int row_step() { return KS == 1 ? 1 : S; }  // patch rows per output row
+};
+
+template <int TM, int TN, int KS, int S, bool INB>
+__global__ __launch_bounds__(256) void conv_rows_bf16(RowsArgs p) {
+  using G = Geo<TM, KS, S>;
+  constexpr int BN = TN * 32;
+  constexpr int ppp = INB ? 4 : 8;   // 16-B pieces per pixel
+  constexpr int cpp = INB ? 8 : 4;   // channels per piece
+  constexpr int NPL = (G::NSLOT * ppp + 255) / 256;    // pieces per thread per chunk
+  constexpr int NWF = (KS * BN * 4 + 255) / 256;        // 16-B weight pieces per thread per stage (KS taps x BN rows x 64 B)
+  __shared__ __attribute__((aligned(16))) unsigned short Ps[G::NSLOT * LDP];
+  __shared__ __attribute__((aligned(16))) unsigned short Ws[KS * BN * LDP];
   __shared__ __attribute__((aligned(16))) float Sst[2 * MAXC];  // (mean, rstd) of the input channels of this image
 
   const int t = threadIdx.x;
-  const int tiles_x = (p.W + TC - 1) / TC, tiles_y = (p.H + TR - 1) / TR;
+  const int Ho = (p.H + 2 * G::PAD - KS) / S + 1, Wo = (p.W + 2 * G::PAD - KS) / S + 1;
+  const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + G::ROWS - 1) / G::ROWS;
   const int tiles_n = (p.Cout + BN - 1) / BN;
   int b = blockIdx.x;
   const int tn = b % tiles_n; b /= tiles_n;
   const int tx = b % tiles_x; b /= tiles_x;
   const int ty = b % tiles_y;
   const long long img = b / tiles_y;
-  const int y0 = ty * TR, x0 = tx * TC, n0 = tn * BN;
+  const int y0 = ty * G::ROWS, x0 = tx * TC, n0 = tn * BN;
   const long long in_img = img * (long long)p.H * p.W * p.Cin;
 
   // ---- loader state (branch-free: out-of-image pixels read a clamped address and are zeroed by a select)
-  constexpr int NPL = INB ? NPH : NPF;  // 16-B pieces per thread per chunk
   int pg[NPL];              // element offset of the piece inside the image (clamped), without the chunk offset
   bool pk[NPL];             // inside the image
-  constexpr int ppp = INB ? 4 : 8;   // pieces per pixel
-  constexpr int cpp = INB ? 8 : 4;   // channels per piece
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int f = t + 256 * i;
-    const int pp = f / ppp, q = f - pp * ppp;
-    const int py = pp / PC, px = pp - py * PC;
-    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    const bool inpatch = pp < NPIX;
-    pk[i] = inpatch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const int sl = f / ppp, q = f - sl * ppp;
+    const int py = sl / G::RS, cs = sl - py * G::RS;
+    const int px = G::SPLITROW ? (cs < G::HALF ? 2 * cs : 2 * (cs - G::HALF) + 1) : cs;
+    const int gy = (KS == 1 ? S * (y0 + py) : S * y0 - G::PAD + py), gx = (KS == 1 ? S * (x0 + px) : S * x0 - G::PAD + px);
+    pk[i] = sl < G::NSLOT && px < G::PC && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
     pg[i] = (cy * p.W + cx) * p.Cin + q * cpp;
   }
@@ -88,11 +102,11 @@ __global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
     const int u = t + 256 * i;
     const int row = u >> 2, part = u & 3;
     const int tap = row / BN, n = row - tap * BN;
-    wk[i] = row < 3 * BN && n0 + n < p.Cout;
+    wk[i] = row < KS * BN && n0 + n < p.Cout;
     wg[i] = min(n0 + n, p.Cout - 1) * p.ldw + tap * p.Cin + part * 8;
   }
 
-  f32x4 rp[NPL];   // fp32 path: 4 channels; bf16 path: 8 packed channels (bit pattern)
+  f32x4 rp[NPL];   // fp32 tensors: 4 channels; bf16 tensors: 8 packed channels (bit pattern)
   u32x4 rw[NWF];
   auto load_patch = [&](int c0) {
     if (INB) {
@@ -130,8 +144,8 @@ __global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
     if (INB) {
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
-        const int f = t + 256 * i, pp = f / ppp;
-        if (pp >= NPIX) continue;
+        const int f = t + 256 * i, sl = f / ppp;
+        if (sl >= G::NSLOT) continue;
         u32x4 w = __builtin_bit_cast(u32x4, rp[i]);
         if (p.in_stats) {
           f32x4 lo = (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16),
@@ -143,23 +157,23 @@ __global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
           w = (u32x4){a[0], a[1], c[0], c[1]};
         }
         if (!pk[i]) w = (u32x4){0u, 0u, 0u, 0u};  // zero padding applies after the normalisation
-        *reinterpret_cast<u32x4*>(&Ps[pp * LDP + (f - pp * ppp) * cpp]) = w;
+        *reinterpret_cast<u32x4*>(&Ps[sl * LDP + (f - sl * ppp) * cpp]) = w;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
-        const int f = t + 256 * i, pp = f / ppp;
-        if (pp >= NPIX) continue;
+        const int f = t + 256 * i, sl = f / ppp;
+        if (sl >= G::NSLOT) continue;
         f32x4 v = rp[i];
         if (p.in_stats) v = norm4(v, sm0, sr0);
         u32x2 w = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
         if (!pk[i]) w = (u32x2){0u, 0u};
-        *reinterpret_cast<u32x2*>(&Ps[pp * LDP + (f - pp * ppp) * cpp]) = w;
+        *reinterpret_cast<u32x2*>(&Ps[sl * LDP + (f - sl * ppp) * cpp]) = w;
       }
     }
   };
   auto load_w = [&](int c0, int kh) {
-    const int base = kh * 3 * p.Cin + c0;
+    const int base = kh * KS * p.Cin + c0;
 #pragma unroll
     for (int i = 0; i < NWF; ++i) rw[i] = *reinterpret_cast<const u32x4*>(p.w + wg[i] + base);
   };
@@ -167,18 +181,17 @@ __global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
 #pragma unroll
     for (int i = 0; i < NWF; ++i) {
       const int u = t + 256 * i, row = u >> 2;
-      if (row >= 3 * BN) continue;
+      if (row >= KS * BN) continue;
       *reinterpret_cast<u32x4*>(&Ws[row * LDP + (u & 3) * 8]) = wk[i] ? rw[i] : (u32x4){0u, 0u, 0u, 0u};
     }
   };
 
   const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, h = lane >> 5;
   // lane bases; everything else in the inner loop is a compile-time offset
-  const unsigned short* Pl = Ps + (wm * TM * PC + r) * LDP + h * 8;
-  const unsigned short* Wl = Ws + (wn * TN * 32 + r) * LDP + h * 8;
+  const unsigned short* Pl = Ps + (G::row_step() * wm * TM * G::RS + r) * LDP + h * 8;
+  const unsigned short* Wl = Ws + r * LDP + h * 8;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -195,23 +208,24 @@ __global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
     store_patch(c * CK);  // (the barrier that ended the previous chunk's last stage made the patch free)
     const bool more = c + 1 < nchunk;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
+    for (int kh = 0; kh < KS; ++kh) {
       store_w();
       __syncthreads();
-      if (kh < 2) {
+      if (kh + 1 < KS) {
         load_w(c * CK, kh + 1);
       } else if (more) {
         load_w((c + 1) * CK, 0);
         load_patch((c + 1) * CK);
       }
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
+      for (int kw = 0; kw < KS; ++kw) {
 #pragma unroll
         for (int ks = 0; ks < CK / 16; ++ks) {
           bf16x8 a[TM], bb[TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i)
-            a[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pl + ((i + kh) * PC + kw) * LDP + ks * 16));
+            a[i] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(Pl + ((G::row_step() * i + kh) * G::RS + G::tap_col(kw)) * LDP + ks * 16));
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             bb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + (kw * BN + j * 32) * LDP + ks * 16));
@@ -228,25 +242,24 @@ __global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
   // ---- epilogue: D[pixel][cout]: cout on the lanes (coalesced 128-B rows), pixels (e&3) + 8(e>>2) + 4h in the registers.
   // A row's address is a wave-uniform base (SGPRs) plus one 32-bit lane offset; the sixteen pixels of a register block
   // differ by compile-time multiples of ldo.
-  const bool interior = x0 + TC <= p.W;
-  const int slots_x = tiles_x;
+  const bool interior = x0 + TC <= Wo;
   const int esz = p.out_bf16 ? 2 : 4;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + r;
+    const int n = n0 + j * 32 + r;
     const bool nok = n < p.Cout;
     const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
     const int lane_off = (4 * h * p.ldo + n) * esz;  // bytes
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int y = y0 + wm * TM + i;  // wave-uniform
-      if (y >= p.H) continue;
-      char* rowp = reinterpret_cast<char*>(p.out) + (((img * p.H + y) * (long long)p.W + x0) * p.ldo) * esz;  // wave-uniform
+      if (y >= Ho) continue;
+      char* rowp = reinterpret_cast<char*>(p.out) + (((img * Ho + y) * (long long)Wo + x0) * p.ldo) * esz;  // wave-uniform
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int dx = (e & 3) + 8 * (e >> 2);
-        if (nok && (interior || x0 + 4 * h + dx < p.W)) {
+        if (nok && (interior || x0 + 4 * h + dx < Wo)) {
           const float v = acc[i][j][e] + bv;
           char* q = rowp + dx * p.ldo * esz + lane_off;
           if (p.out_bf16) *reinterpret_cast<unsigned short*>(q) = mvt_bf16_bits(v);
@@ -259,7 +272,135 @@ __global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (h == 0 && nok) {
-          float* pp = p.out_part + ((img * p.slots + (long long)y * slots_x + tx) * p.Cout + n) * 2;
+          float* pp = p.out_part + ((img * p.slots + (long long)y * tiles_x + tx) * p.Cout + n) * 2;
+          pp[0] = s1;
+          pp[1] = s2;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 7x7 / stride 2 / pad 3 stem (BasicEncoder.conv1, blocks.py:222) on the same 8 x 32 pixel tiles.  The input is the
+// normalised RGB image with channels padded to four (fp32 [n][H][W][4]); the weights are [Cout][kh][8][4] bf16 (zero for
+// kw = 7 and c = 3), i.e. K = 7 x 32.  A 32-wide k-group is one filter row; lane (r, h) of a 16-wide MFMA step reads two
+// neighbouring input pixels (8 bf16 = 16 B), and neighbouring output pixels are two input pixels apart, so the A fragments
+// of a wave are consecutive 16-B words of a patch row: conflict-free ds_read_b128 with no im2col buffer at all.  The
+// generic im2col GEMM spent 680 us per 24 images on this layer (45 GFLOP); the output write is the only real cost.
+constexpr int SPR = 2 * TR + 5, SPC = 2 * TC + 6;   // 21 x 70 patch pixels (one spare column keeps rows 16-B aligned)
+constexpr int SNP = SPR * SPC;
+constexpr int SKW = 7 * 32;                         // K
+constexpr int SLW = SKW + 8;                        // LDS weight row stride (bf16): 464 B, conflict-free b128 reads
+
+template <int TN>
+__global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
+  constexpr int TM = 2, BN = TN * 32;
+  constexpr int NPL = (SNP + 255) / 256;
+  constexpr int NWF = (BN * (SKW / 8) + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned short Ps[SNP * 4];
+  __shared__ __attribute__((aligned(16))) unsigned short Ws[BN * SLW];
+  const int t = threadIdx.x;
+  const int Ho = (p.H + 6 - 7) / 2 + 1, Wo = (p.W + 6 - 7) / 2 + 1;
+  const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + TR - 1) / TR;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const long long img = b / tiles_y;
+  const int y0 = ty * TR, x0 = tx * TC;
+  const float* in = p.in + img * (long long)p.H * p.W * 4;
+
+  f32x4 rp[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int f = t + 256 * i;
+    const int py = f / SPC, px = f - py * SPC;
+    const int gy = 2 * y0 - 3 + py, gx = 2 * x0 - 3 + px;
+    const bool ok = f < SNP && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((long long)cy * p.W + cx) * 4);
+    rp[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  u32x4 rw[NWF];
+#pragma unroll
+  for (int i = 0; i < NWF; ++i) {
+    const int u = t + 256 * i;
+    const int n = u / (SKW / 8), part = u - n * (SKW / 8);
+    rw[i] = *reinterpret_cast<const u32x4*>(p.w + (long long)min(n, p.Cout - 1) * p.ldw + part * 8);
+    if (n >= p.Cout) rw[i] = (u32x4){0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int f = t + 256 * i;
+    if (f < SNP) *reinterpret_cast<u32x2*>(&Ps[f * 4]) = __builtin_bit_cast(u32x2, __builtin_convertvector(rp[i], bf16x4));
+  }
+#pragma unroll
+  for (int i = 0; i < NWF; ++i) {
+    const int u = t + 256 * i;
+    const int n = u / (SKW / 8), part = u - n * (SKW / 8);
+    if (n < BN) *reinterpret_cast<u32x4*>(&Ws[n * SLW + part * 8]) = rw[i];
+  }
+  __syncthreads();
+
+  const int lane = t & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const unsigned short* Pl = Ps + ((wm * TM * 2) * SPC + 2 * r + 2 * h) * 4;
+  const unsigned short* Wl = Ws + r * SLW + h * 8;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[TM], bb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pl + ((2 * i + kh) * SPC + 4 * ks) * 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + j * 32 * SLW + kh * 32 + ks * 16));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const bool interior = x0 + TC <= Wo;
+  const int esz = p.out_bf16 ? 2 : 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = j * 32 + r;
+    const bool nok = n < p.Cout;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+    const int lane_off = (4 * h * p.ldo + n) * esz;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int y = y0 + wm * TM + i;
+      if (y >= Ho) continue;
+      char* rowp = reinterpret_cast<char*>(p.out) + (((img * Ho + y) * (long long)Wo + x0) * p.ldo) * esz;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dx = (e & 3) + 8 * (e >> 2);
+        if (nok && (interior || x0 + 4 * h + dx < Wo)) {
+          const float v = acc[i][j][e] + bv;
+          char* q = rowp + dx * p.ldo * esz + lane_off;
+          if (p.out_bf16) *reinterpret_cast<unsigned short*>(q) = mvt_bf16_bits(v);
+          else *reinterpret_cast<float*>(q) = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+      }
+      if (p.out_part) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0 && nok) {
+          float* pp = p.out_part + ((img * p.slots + (long long)y * tiles_x + tx) * p.Cout + n) * 2;
           pp[0] = s1;
           pp[1] = s2;
         }
@@ -273,32 +414,61 @@ __global__ __launch_bounds__(256) void conv3x3_rows_bf16(RowsArgs p) {
 // slots of the fused statistics: one per 32-pixel row segment
 __attribute__((visibility("hidden"))) int mvt_detail_conv_rows_slots(int H, int W) { return H * (int)mvt_cdiv(W, TC); }
 
-__attribute__((visibility("hidden"))) int mvt_detail_conv3x3_rows(const void* in, const unsigned short* w, int ldw, const float* bias,
-                                                                  void* out, int n, int H, int W, int Cin, int Cout, int ldo, int act,
-                                                                  int io_flags, const float* in_stats, float* out_partial,
-                                                                  hipStream_t stream) {
-  MVT_REQUIRE((!in_stats || Cin <= MAXC) && Cin % CK == 0 && (long long)H * W * Cin < (1LL << 31) && (long long)Cout * ldw < (1LL << 31) && act == MVT_ACT_NONE);
+// 3x3 (pad 1) or 1x1 (pad 0) convolution, stride 1 or 2, Cin % 32 == 0, bf16 mode
+__attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, const unsigned short* w, int ldw, const float* bias, void* out,
+                                                               int n, int H, int W, int Cin, int Cout, int ksize, int stride, int ldo,
+                                                               int io_flags, const float* in_stats, float* out_partial,
+                                                               hipStream_t stream) {
+  MVT_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2));
+  MVT_REQUIRE((!in_stats || Cin <= MAXC) && Cin % CK == 0 && (long long)H * W * Cin < (1LL << 31) && (long long)Cout * ldw < (1LL << 31));
   MVT_REQUIRE((long long)(TC + 8) * ldo * 4 < (1LL << 31));
+  const int pad = ksize == 3 ? 1 : 0;
+  const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
   RowsArgs a{};
   a.in = (const float*)in; a.w = w; a.bias = bias; a.out = (float*)out; a.in_stats = in_stats; a.out_part = out_partial;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldw = ldw; a.ldo = ldo;
-  a.slots = mvt_detail_conv_rows_slots(H, W);
+  a.slots = mvt_detail_conv_rows_slots(Ho, Wo);
   a.in_bf16 = io_flags & MVT_IO_IN_BF16 ? 1 : 0;
   a.out_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
-  const long long tiles = (long long)n * mvt_cdiv(H, TR) * mvt_cdiv(W, TC);
-  MVT_REQUIRE(tiles * mvt_cdiv(Cout, 64) < (1LL << 31));
-#define LAUNCH(TM_, TN_, WM_, WN_, BN_)                                                                                       \
-  do {                                                                                                                       \
-    const dim3 grid((unsigned)(tiles * mvt_cdiv(Cout, BN_)));                                                                \
-    if (a.in_bf16) hipLaunchKernelGGL((conv3x3_rows_bf16<TM_, TN_, WM_, WN_, true>), grid, dim3(256), 0, stream, a);         \
-    else hipLaunchKernelGGL((conv3x3_rows_bf16<TM_, TN_, WM_, WN_, false>), grid, dim3(256), 0, stream, a);                  \
+  const bool n96 = Cout % 64 != 0 && Cout % 96 == 0;
+  const int bn = n96 ? 96 : 64;
+  // (64-channel tiles keep three workgroups per CU with bf16 tensors: measured 1.4x faster than 128-channel tiles at one per CU)
+#define LAUNCH(TM_, KS_, S_)                                                                                                        \
+  do {                                                                                                                             \
+    const long long tiles = (long long)n * mvt_cdiv(Ho, 4 * TM_) * mvt_cdiv(Wo, TC) * mvt_cdiv(Cout, bn);                          \
+    MVT_REQUIRE(tiles < (1LL << 31));                                                                                              \
+    const dim3 grid((unsigned)tiles);                                                                                              \
+    if (n96) {                                                                                                                     \
+      if (a.in_bf16) hipLaunchKernelGGL((conv_rows_bf16<TM_, 3, KS_, S_, true>), grid, dim3(256), 0, stream, a);                   \
+      else hipLaunchKernelGGL((conv_rows_bf16<TM_, 3, KS_, S_, false>), grid, dim3(256), 0, stream, a);                            \
+    } else {                                                                                                                       \
+      if (a.in_bf16) hipLaunchKernelGGL((conv_rows_bf16<TM_, 2, KS_, S_, true>), grid, dim3(256), 0, stream, a);                   \
+      else hipLaunchKernelGGL((conv_rows_bf16<TM_, 2, KS_, S_, false>), grid, dim3(256), 0, stream, a);                            \
+    }                                                                                                                              \
   } while (0)
-  static const int force = getenv("MVT_ROWS_CFG") ? atoi(getenv("MVT_ROWS_CFG")) : 0;  // tuning override
-  if (force == 1) LAUNCH(2, 2, 4, 1, 64);
-  else if (force == 2) LAUNCH(4, 2, 2, 2, 128);
-  else if (force == 3) LAUNCH(2, 4, 4, 1, 128);
-  else if (Cout % 64 != 0 && Cout % 96 == 0) LAUNCH(2, 3, 4, 1, 96);
-  else LAUNCH(2, 2, 4, 1, 64);  // three workgroups per CU with bf16 tensors: measured 1.4x faster than the 128-channel tiles at one per CU
+  if (ksize == 3 && stride == 1) LAUNCH(2, 3, 1);
+  else if (ksize == 3) LAUNCH(1, 3, 2);   // the stride-2 patch is four times larger per output pixel: 4 x 32 pixel tiles
+  else if (stride == 1) LAUNCH(2, 1, 1);
+  else LAUNCH(2, 1, 2);
 #undef LAUNCH
+  return mvt_launch_status();
+}
+
+// 7x7 stride-2 pad-3 stem with Cin padded to 4 and Cout <= 64 (bf16 mode)
+__attribute__((visibility("hidden"))) int mvt_detail_stem7x7_rows(const float* in, const unsigned short* w, int ldw, const float* bias,
+                                                                  void* out, int n, int H, int W, int Cout, int ldo, int io_flags,
+                                                                  float* out_partial, hipStream_t stream) {
+  MVT_REQUIRE(Cout > 0 && Cout <= 64 && ldw >= SKW && (long long)H * W * 4 < (1LL << 31) && !(io_flags & MVT_IO_IN_BF16));
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  RowsArgs a{};
+  a.in = in; a.w = w; a.bias = bias; a.out = (float*)out; a.in_stats = nullptr; a.out_part = out_partial;
+  a.H = H; a.W = W; a.Cin = 4; a.Cout = Cout; a.ldw = ldw; a.ldo = ldo;
+  a.slots = mvt_detail_conv_rows_slots(Ho, Wo);
+  a.in_bf16 = 0;
+  a.out_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
+  const long long tiles = (long long)n * mvt_cdiv(Ho, TR) * mvt_cdiv(Wo, TC);
+  MVT_REQUIRE(tiles < (1LL << 31) && (long long)(TC + 8) * ldo * 4 < (1LL << 31));
+  if (Cout <= 32) hipLaunchKernelGGL((stem7x7_rows_bf16<1>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((stem7x7_rows_bf16<2>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
   return mvt_launch_status();
 }

@@ -829,14 +829,19 @@ extern "C" int mvt_gemm_bf16(const float* A, int lda, const unsigned short* Whi,
 }
 
 int mvt_detail_conv_rows_slots(int H, int W);
-int mvt_detail_conv3x3_rows(const void* in, const unsigned short* w, int ldw, const float* bias, void* out, int n, int H, int W, int Cin,
-                            int Cout, int ldo, int act, int io_flags, const float* in_stats, float* out_partial, hipStream_t stream);
+int mvt_detail_stem7x7_rows(const float* in, const unsigned short* w, int ldw, const float* bias, void* out, int n, int H, int W, int Cout,
+                            int ldo, int io_flags, float* out_partial, hipStream_t stream);
+int mvt_detail_conv_rows(const void* in, const unsigned short* w, int ldw, const float* bias, void* out, int n, int H, int W, int Cin,
+                         int Cout, int ksize, int stride, int ldo, int io_flags, const float* in_stats, float* out_partial,
+                         hipStream_t stream);
 
 extern "C" int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad, int split) {
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
-  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0)
-    return split ? (int)(mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4) : mvt_detail_conv_rows_slots(Ho, Wo);
+  if (!split && Cin % 32 == 0 && KH == KW && ((KH == 3 && pad == 1) || (KH == 1 && pad == 0)) && stride <= 2)
+    return mvt_detail_conv_rows_slots(Ho, Wo);  // row-tile kernels
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0) return (int)(mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4);
+  if (!split && Cin == 4 && KH == 7 && KW == 7 && stride == 2 && pad == 3) return mvt_detail_conv_rows_slots(Ho, Wo);  // stem kernel
   return ((long long)Ho * Wo) % 256 == 0 ? Ho * Wo / 32 : 0;  // im2col tiles are <= 256 rows: they must not straddle images
 }
 
@@ -866,7 +871,9 @@ extern "C" int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, cons
   a.ldw = a.nk * BKB;  // weights are [Cout][round_up(K, 64)], zero padded
   a.lda = 0;
   const bool halo = KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0;
-  MVT_REQUIRE(!in_stats || (halo && ((uintptr_t)in_stats % 16 == 0)));  // normalise-on-load exists in the halo kernel only
+  // bf16 mode: every 3x3 (pad 1) and 1x1 (pad 0) convolution with Cin % 32 == 0 runs on the row-tile kernels (conv_rows.hip)
+  const bool rows = !wt_lo && act == MVT_ACT_NONE && Cin % 32 == 0 && KH == KW && ((KH == 3 && pad == 1) || (KH == 1 && pad == 0));
+  MVT_REQUIRE(!in_stats || ((halo || rows) && ((uintptr_t)in_stats % 16 == 0)));  // normalise-on-load: halo / row-tile kernels only
   a.in_stats = in_stats;
   a.out_part = out_partial;
   a.a_bf16 = io_flags & MVT_IO_IN_BF16 ? 1 : 0;
@@ -874,10 +881,12 @@ extern "C" int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, cons
   MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16)) == 0 && (!io_flags || !wt_lo));  // bf16 tensors: bf16 mode only
   MVT_REQUIRE(!a.a_bf16 || (Cin % 32 == 0 && (uintptr_t)in % 8 == 0));                          // (the stem reads fp32 RGB)
   a.slots = mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, wt_lo != nullptr);
-  MVT_REQUIRE(!out_partial || a.slots > 0);
-  if (halo && !wt_lo && act == MVT_ACT_NONE)
-    return mvt_detail_conv3x3_rows(in, wt_hi, a.ldw, bias, out, n, H, W, Cin, Cout, ldo, act, io_flags, in_stats, out_partial,
-                                   mvt_stream(stream));
+  MVT_REQUIRE(!out_partial || (a.slots > 0 && (wt_lo || act == MVT_ACT_NONE)));
+  if (!wt_lo && Cin == 4 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout <= 64 && act == MVT_ACT_NONE)
+    return mvt_detail_stem7x7_rows((const float*)in, wt_hi, a.ldw, bias, out, n, H, W, Cout, ldo, io_flags, out_partial, mvt_stream(stream));
+  if (rows)
+    return mvt_detail_conv_rows(in, wt_hi, a.ldw, bias, out, n, H, W, Cin, Cout, KH, stride, ldo, io_flags, in_stats, out_partial,
+                                mvt_stream(stream));
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0 && (long long)n * mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4 < (1LL << 31))
     return wt_lo ? launch_conv3x3_halo<true>(a, n, mvt_stream(stream)) : launch_conv3x3_halo<false>(a, n, mvt_stream(stream));
   return wt_lo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));

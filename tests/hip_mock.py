@@ -110,8 +110,12 @@ def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
 
 def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False):
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    if not split and Cin % 32 == 0 and KH == KW and ((KH == 3 and pad == 1) or (KH == 1 and pad == 0)):
+        return Ho * ((Wo + 31) // 32)
     if KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cin % 32 == 0:
-        return ((Ho + 7) // 8) * ((Wo + 15) // 16) * 4 if split else Ho * ((Wo + 31) // 32)
+        return ((Ho + 7) // 8) * ((Wo + 15) // 16) * 4
+    if not split and Cin == 4 and KH == 7 and KW == 7 and stride == 2 and pad == 3:
+        return Ho * ((Wo + 31) // 32)
     return Ho * Wo // 32 if (Ho * Wo) % 256 == 0 else 0
 
 

@@ -141,7 +141,10 @@ def test_conv2d_fused_instnorm(hip, cfg, prec):
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     halo = k == 3 and s == 1
     slots = hip.conv2d_stat_slots(H, W, cin, k, k, s, p, prec == "bf16x3")
-    assert slots == ((((Ho + 7) // 8) * ((Wo + 15) // 16) * 4 if prec == "bf16x3" else Ho * ((Wo + 31) // 32)) if halo else Ho * Wo // 32)
+    if prec == "bf16":  # row-tile kernels: one slot per 32-pixel row segment
+        assert slots == Ho * ((Wo + 31) // 32)
+    else:
+        assert slots == (((Ho + 7) // 8) * ((Wo + 15) // 16) * 4 if halo else Ho * Wo // 32)
     xin = G(x)
     in_st = None
     if halo:  # normalise-on-load against an explicit normalise pass

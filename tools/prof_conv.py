@@ -15,14 +15,15 @@ dev = "cuda"
 a = [int(v) for v in sys.argv[1:9]] if len(sys.argv) >= 9 else [16, 256, 256, 64, 64, 3, 1, 1]
 n, H, W, Cin, Cout, k, s, p = a
 bf = len(sys.argv) > 9 and sys.argv[9] == "1"
-K = k * k * Cin
+stem = Cin == 4
+K = k * 32 if stem else k * k * Cin
 ld = (K + 63) // 64 * 64
 w = torch.zeros(Cout, ld, device=dev)
 w[:, :K] = torch.randn(Cout, K, device=dev) / math.sqrt(K)
 hi = torch.empty(Cout, ld, device=dev, dtype=torch.int16)
 hip.split_bf16(w, hi, None, w.numel())
 dt = torch.bfloat16 if bf else torch.float32
-x = torch.randn(n, H, W, Cin, device=dev).to(dt)
+x = torch.randn(n, H, W, Cin, device=dev).to(torch.float32 if stem else dt)
 Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 out = torch.empty(n, Ho, Wo, Cout, device=dev, dtype=dt)
 b = torch.randn(Cout, device=dev)
@@ -38,5 +39,5 @@ for it in range(6):
 ev1.record()
 torch.cuda.synchronize()
 t = ev0.elapsed_time(ev1) / 5 * 1e3
-fl = 2.0 * n * Ho * Wo * Cout * K
+fl = 2.0 * n * Ho * Wo * Cout * (147 if stem else K)
 print(f"conv n={n} {H}x{W} {Cin}->{Cout} k{k}s{s} bf16_tensors={bf}: {t:.1f} us  {fl / t / 1e6:.0f} TFLOP/s")
