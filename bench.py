@@ -48,7 +48,7 @@ def cpu_baseline(args):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, args.cpu_threads))  # the GPU box gives one GPU a 16-core CPU share
     torch.set_num_threads(cores)
-    V, T, H, W, N = 4, 12, args.cpu_hw, args.cpu_hw, 128
+    V, T, H, W, N = 4, 12, args.cpu_hw, args.cpu_hw, 256  # the workload's views / image size, one window, a quarter of the queries
     clip = synth.make_clip(1234, V=V, T=T, H=H, W=W, N=N)
     cfg = O.TrackerConfig()
     Wt = O.make_weights(cfg, 0)
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="bf16",
                     help="matrix-core arithmetic of convs/linears; BASELINE.json quotes this config in bf16")
-    ap.add_argument("--cpu-hw", type=int, default=256)
+    ap.add_argument("--cpu-hw", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
