@@ -155,6 +155,14 @@ def main():
         kern_ms = float(np.mean([m for m, _ in full])) if full else float("nan")
         alg = model.corr_n_levels * corr_algorithmic_bytes(Nq * model.S, model.corr_neighbors, model.latent_dim)
         achieved = alg / (kern_ms * 1e-3) / 1e9 if full else float("nan")
+        # HBM traffic of the roofline kernel: PMC measurement committed under profiles/ (tools/pmc_traffic.sh; counters cannot
+        # be collected from inside the timed run).  Only quoted for the workload it was measured on.
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_corr_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("algorithmic_bytes_per_launch") == alg:
+                traffic = tj["traffic_bytes_per_launch"]
         out = {
             "metric": "query-points*frames/sec, 4-view 24-frame 512x512 @1024 queries",
             "value": value, "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,8 +173,11 @@ def main():
                                    f"3 windows, random-init weights (seeded recipe)",
                        "queries_total": Nq * world, "parallelism": f"query-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "corr_gather_dot_kernel<32>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms, "launches_timed": len(full)},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms, "launches_timed": len(full),
+                         # launches of the last window run alone; earlier ones share HBM with the encoder of the later
+                         # frames on the second stream (the average above includes that contention)
+                         "min_launch_ms": float(np.min([m for m, _ in full])) if full else None},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
