@@ -224,6 +224,22 @@ int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int 
  * indices, ascending by (d2, index); indices are clamped to [0, P) (only NaN queries can be out of range). */
 int mvt_knn_merge(const unsigned long long* keys, int N, int S, int K, int nseg, long long P, int* idx_out,
                   void* stream);
+/* Scan / merge of several pyramid levels in ONE launch each (grid.y = level).  After the first refinement iteration every
+ * level is seeded by its own previous neighbours (seed_idx [N][S][seed_k], same-level indices), so the scans are
+ * independent; one launch removes three launch / tail latencies per iteration.  Semantics per level = mvt_knn_scan /
+ * mvt_knn_merge.  seed_k == 0: unseeded (every seed_idx NULL). */
+typedef struct mvt_knn_level {
+  const float* xyz;         /* [T][P][4] */
+  long long P;
+  unsigned long long* keys; /* [N][S][nseg][K] */
+  const int* seed_idx;      /* [N][S][seed_k] or NULL */
+  const float* tile_box;    /* from mvt_tile_aabb(grid_w, grid_h) or NULL */
+  int nseg, grid_w, grid_h;
+  int* idx_out;             /* [N][S][K] (merge) */
+} mvt_knn_level;
+int mvt_knn_scan_levels(int levels, const mvt_knn_level* lv, const float* coords, int N, int S, int frame0, int frame_step,
+                        int T, int K, int seed_k, void* stream);
+int mvt_knn_merge_levels(int levels, const mvt_knn_level* lv, int N, int S, int K, void* stream);
 /* Gather-dot correlation for `levels` pyramid levels in ONE launch (grid.y = level).  Host arrays of per-level
  * DEVICE pointers: xyz[l] [T][P_l][4], fvec[l] [T][P_l][C] (C in {32,64,128,256}, groups == 1), idx[l]
  * [N][S][K] int32 from mvt_knn_merge, P[l].  For k < K:

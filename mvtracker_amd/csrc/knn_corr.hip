@@ -153,12 +153,11 @@ __global__ __launch_bounds__(256) void tile_aabb_kernel(const float* __restrict_
 }
 
 template <int Q>
-__global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ xyz, long long P, const float* __restrict__ coords,
-                                                       int N, int S, int frame0, int frame_step, int T, int K, int nseg,
-                                                       unsigned long long* __restrict__ keys, int qgroups,
-                                                       const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch,
-                                                       int seed_fw, int seed_fh, const float* __restrict__ box, int grid_w, int grid_h) {
-  __shared__ unsigned long long lds[4 * Q * CAP];
+__device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const float* __restrict__ xyz, long long P,
+                                              const float* __restrict__ coords, int N, int S, int frame0, int frame_step, int T, int K,
+                                              int nseg, unsigned long long* __restrict__ keys, int qgroups,
+                                              const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch, int seed_fw,
+                                              int seed_fh, const float* __restrict__ box, int grid_w, int grid_h) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // task id -> (segment, query group, slot); segment fastest so that heavy frames spread over CUs
   long long task = (long long)blockIdx.x * 4 + wave;
@@ -302,10 +301,36 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   }
 }
 
+template <int Q>
+__global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ xyz, long long P, const float* __restrict__ coords,
+                                                       int N, int S, int frame0, int frame_step, int T, int K, int nseg,
+                                                       unsigned long long* __restrict__ keys, int qgroups,
+                                                       const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch,
+                                                       int seed_fw, int seed_fh, const float* __restrict__ box, int grid_w, int grid_h) {
+  __shared__ unsigned long long lds[4 * Q * CAP];
+  knn_scan_body<Q>(lds, xyz, P, coords, N, S, frame0, frame_step, T, K, nseg, keys, qgroups, seed_idx, seed_k, seed_cw, seed_ch, seed_fw,
+                   seed_fh, box, grid_w, grid_h);
+}
+
+// All pyramid levels of one refinement iteration in ONE launch (grid.y = level): after the first iteration every level is
+// seeded by its own previous neighbours, so the four scans are independent and each alone is launch / tail latency.
+struct KnnLevels {
+  mvt_knn_level lv[8];
+};
+
+template <int Q>
+__global__ __launch_bounds__(256) void knn_scan_levels_kernel(KnnLevels a, const float* __restrict__ coords, int N, int S, int frame0,
+                                                              int frame_step, int T, int K, int qgroups, int seed_k) {
+  __shared__ unsigned long long lds[4 * Q * CAP];
+  const mvt_knn_level L = a.lv[blockIdx.y];
+  knn_scan_body<Q>(lds, L.xyz, L.P, coords, N, S, frame0, frame_step, T, K, L.nseg, L.keys, qgroups, L.seed_idx, seed_k, 0, 0, 0, 0,
+                   L.tile_box, L.grid_w, L.grid_h);
+}
+
 // Merge the nseg per-segment lists of one (track, slot) into its K nearest neighbour indices.  Every lane holds
 // one key; its rank among the E = nseg*K keys is counted with wave-uniform readlane broadcasts (keys are unique).
-__global__ __launch_bounds__(256) void knn_merge_kernel(const unsigned long long* __restrict__ keys, long long rows, int K, int nseg,
-                                                        long long P, int* __restrict__ idx_out) {
+__device__ __forceinline__ void knn_merge_body(const unsigned long long* __restrict__ keys, long long rows, int K, int nseg, long long P,
+                                               int* __restrict__ idx_out) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -327,6 +352,16 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const unsigned long long
     if ((long long)idx >= P) idx = (unsigned)(P - 1);  // only reachable with NaN coordinates; stay in bounds
     idx_out[row * K + rank] = (int)idx;
   }
+}
+
+__global__ __launch_bounds__(256) void knn_merge_kernel(const unsigned long long* __restrict__ keys, long long rows, int K, int nseg,
+                                                        long long P, int* __restrict__ idx_out) {
+  knn_merge_body(keys, rows, K, nseg, P, idx_out);
+}
+
+__global__ __launch_bounds__(256) void knn_merge_levels_kernel(KnnLevels a, long long rows, int K) {
+  const mvt_knn_level L = a.lv[blockIdx.y];
+  knn_merge_body(L.keys, rows, K, L.nseg, L.P, L.idx_out);
 }
 
 struct CorrLevels {
@@ -503,6 +538,61 @@ extern "C" int mvt_knn_scan(const float* xyz, long long P, const float* coords, 
     default: return MVT_ERR_ARG;
   }
 #undef LAUNCH
+  return mvt_launch_status();
+}
+
+static int knn_check_level(const mvt_knn_level& L, int K) {
+  MVT_REQUIRE(L.xyz && L.keys && L.P >= K && L.P < (1LL << 31) && L.nseg >= 1 && L.nseg * K <= 64);
+  MVT_REQUIRE((L.grid_w == 0 && L.grid_h == 0) ||
+              (L.grid_w > 0 && L.grid_h > 0 && L.grid_w % 8 == 0 && L.grid_h % 8 == 0 && L.P % ((long long)L.grid_w * L.grid_h) == 0));
+  const long long ntiles = (L.P + 63) / 64, tper = (ntiles + L.nseg - 1) / L.nseg;
+  MVT_REQUIRE(tper * (L.nseg - 1) < ntiles);
+  return MVT_OK;
+}
+
+extern "C" int mvt_knn_scan_levels(int levels, const mvt_knn_level* lv, const float* coords, int N, int S, int frame0, int frame_step,
+                                   int T, int K, int seed_k, void* stream) {
+  MVT_REQUIRE(levels >= 1 && levels <= 8 && lv && coords && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0);
+  MVT_REQUIRE(K >= 1 && K <= 16 && (seed_k == 0 || (seed_k >= K && seed_k <= 64)));
+  KnnLevels a{};
+  int max_nseg = 1;
+  bool boxes = true;
+  for (int l = 0; l < levels; ++l) {
+    if (int rc = knn_check_level(lv[l], K)) return rc;
+    MVT_REQUIRE((lv[l].seed_idx != nullptr) == (seed_k > 0));
+    a.lv[l] = lv[l];
+    max_nseg = lv[l].nseg > max_nseg ? lv[l].nseg : max_nseg;
+    boxes = boxes && lv[l].tile_box;
+  }
+  static const int q_env = getenv("MVT_KNN_Q") ? atoi(getenv("MVT_KNN_Q")) : 0;
+  const int Q = q_env ? q_env : (boxes ? 2 : 8);
+  const int qgroups = (N + Q - 1) / Q;
+  const dim3 grid((unsigned)mvt_cdiv((long long)qgroups * S * max_nseg, 4), (unsigned)levels);
+#define LAUNCH(QQ)                                                                                                              \
+  hipLaunchKernelGGL((knn_scan_levels_kernel<QQ>), grid, dim3(256), 0, mvt_stream(stream), a, coords, N, S, frame0, frame_step, T, K, \
+                     qgroups, seed_k)
+  switch (Q) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    default: return MVT_ERR_ARG;
+  }
+#undef LAUNCH
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_knn_merge_levels(int levels, const mvt_knn_level* lv, int N, int S, int K, void* stream) {
+  MVT_REQUIRE(levels >= 1 && levels <= 8 && lv && N > 0 && S > 0 && K >= 1 && K <= 16);
+  KnnLevels a{};
+  for (int l = 0; l < levels; ++l) {
+    if (int rc = knn_check_level(lv[l], K)) return rc;
+    MVT_REQUIRE(lv[l].idx_out);
+    a.lv[l] = lv[l];
+  }
+  const long long rows = (long long)N * S;
+  hipLaunchKernelGGL(knn_merge_levels_kernel, dim3((unsigned)mvt_cdiv(rows, 4), (unsigned)levels), dim3(256), 0, mvt_stream(stream), a,
+                     rows, K);
   return mvt_launch_status();
 }
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     "mvt_tile_aabb": [P, LL, I, I, I, P, P],
     "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P, I, I, P],
     "mvt_knn_merge": [P, I, I, I, I, LL, P, P],
+    "mvt_knn_scan_levels": [I, P, P, I, I, I, I, I, I, I, P],
+    "mvt_knn_merge_levels": [I, P, I, I, I, P],
     "mvt_corr_gather_dot": [I, P, P, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
     "mvt_knn1_gather": [P, LL, I, P, I, I, I, P, P, P],
     "mvt_window_corr": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
@@ -241,6 +243,32 @@ def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_i
     box / grid: tile bounding boxes from ``tile_aabb`` (same grid) for culling."""
     _call("mvt_knn_scan", _ptr(xyz), Pn, _ptr(coords), N, S, frame0, frame_step, T, K, nseg, _ptr(keys), _ptr(seed_idx), seed_k,
           *seed_dims, _ptr(box), grid[0], grid[1], _stream())
+
+
+class KnnLevel(C.Structure):
+    """mvt_knn_level of include/mvtracker_hip.h."""
+    _fields_ = [("xyz", C.c_void_p), ("P", C.c_longlong), ("keys", C.c_void_p), ("seed_idx", C.c_void_p), ("tile_box", C.c_void_p),
+                ("nseg", C.c_int), ("grid_w", C.c_int), ("grid_h", C.c_int), ("idx_out", C.c_void_p)]
+
+
+def _knn_levels(levels):
+    arr = (KnnLevel * len(levels))()
+    for i, lv in enumerate(levels):
+        g = lv.get("grid", (0, 0))
+        arr[i] = KnnLevel(_ptr(lv["xyz"]), lv["P"], _ptr(lv["keys"]), _ptr(lv.get("seed_idx")), _ptr(lv.get("box")), lv["nseg"], g[0], g[1],
+                          _ptr(lv.get("idx_out")))
+    return arr
+
+
+def knn_scan_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k=0):
+    """levels: list of dicts(xyz, P, keys, nseg[, seed_idx, box, grid, idx_out]); one launch for all of them."""
+    arr = _knn_levels(levels)
+    _call("mvt_knn_scan_levels", len(levels), C.cast(arr, C.c_void_p), _ptr(coords), N, S, frame0, frame_step, T, K, seed_k, _stream())
+
+
+def knn_merge_levels(levels, N, S, K):
+    arr = _knn_levels(levels)
+    _call("mvt_knn_merge_levels", len(levels), C.cast(arr, C.c_void_p), N, S, K, _stream())
 
 
 def knn_merge(keys, N, S, K, nseg, Pn, idx_out):

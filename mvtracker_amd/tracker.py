@@ -617,17 +617,22 @@ class MVTracker(nn.Module):
         idx = torch.empty(L, n, S, K, device=dev, dtype=torch.int32)
         grid = [tuple(store["xyz"][lvl].shape[2:4]) for lvl in range(L)]  # per-view (h, w) of each level
         preds = []
+        levels = [dict(xyz=store["xyz"][lvl], P=store["P"][lvl], keys=keys[lvl], nseg=nsegs[lvl], seed_idx=idx[lvl], box=store["box"][lvl],
+                       grid=store["tile_grid"][lvl], idx_out=idx[lvl]) for lvl in range(L)]
         for it in range(iters):
-            for lvl in reversed(range(L)):  # coarse to fine: level l+1's neighbours bound level l's first scan
-                P = store["P"][lvl]
-                seed = {}
-                if it > 0:
-                    seed = dict(seed_idx=idx[lvl], seed_k=K)
-                elif lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
-                    seed = dict(seed_idx=idx[lvl + 1], seed_k=K, seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
-                hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl], box=store["box"][lvl],
-                             grid=store["tile_grid"][lvl], **seed)
-                hip.knn_merge(keys[lvl], n, S, K, nsegs[lvl], P, idx[lvl])
+            if it > 0:
+                # every level is seeded by its own previous neighbours: the four scans are independent -> one launch
+                hip.knn_scan_levels(levels, coords, n, S, frame0, 1, T, K, seed_k=K)
+                hip.knn_merge_levels(levels, n, S, K)
+            else:
+                for lvl in reversed(range(L)):  # coarse to fine: level l+1's neighbours bound level l's first scan
+                    P = store["P"][lvl]
+                    seed = {}
+                    if lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
+                        seed = dict(seed_idx=idx[lvl + 1], seed_k=K, seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
+                    hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl], box=store["box"][lvl],
+                                 grid=store["tile_grid"][lvl], **seed)
+                    hip.knn_merge(keys[lvl], n, S, K, nsegs[lvl], P, idx[lvl])
             hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0, 1,
                                 T, K, fcorr, Fc, 0)
             hip.token_assemble(coords, fcorr, Fc, ffeats, C, mask_vis, pos, pk["time_embed"], n, S, E, x, ldx)

@@ -275,6 +275,17 @@ def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_i
             kv[:, s, g, :kk] = torch.topk(seg, kk, dim=1, largest=False, sorted=True).values
 
 
+def knn_scan_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k=0):
+    for lv in levels:
+        knn_scan(lv["xyz"], lv["P"], coords, N, S, frame0, frame_step, T, K, lv["nseg"], lv["keys"], seed_idx=lv.get("seed_idx"),
+                 seed_k=seed_k, box=lv.get("box"), grid=lv.get("grid", (0, 0)))
+
+
+def knn_merge_levels(levels, N, S, K):
+    for lv in levels:
+        knn_merge(lv["keys"], N, S, K, lv["nseg"], lv["P"], lv["idx_out"])
+
+
 def knn_merge(keys, N, S, K, nseg, Pn, idx_out):
     kv = torch.as_strided(keys, (N, S, nseg * K), (S * nseg * K, nseg * K, 1))
     idx = (torch.sort(kv, dim=2).values[:, :, :K] & 0xFFFFFFFF).clamp(max=Pn - 1)
@@ -379,6 +390,6 @@ def install(monkeypatch):
     from mvtracker_amd import hip
     me = sys.modules[__name__]
     for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
-                 "depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
+                 "depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

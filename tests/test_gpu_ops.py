@@ -579,6 +579,62 @@ def test_knn_tile_culling_is_exact(hip, patch, nseg):
     assert torch.equal(idx2.permute(1, 0, 2).cpu().long(), ref2)
 
 
+def test_knn_levels_one_launch(hip):
+    """mvt_knn_scan_levels / mvt_knn_merge_levels == the per-level calls (seeded and unseeded)."""
+    g = torch.Generator().manual_seed(31)
+    B, M, K = 2, 37, 16
+    grids = [(16, 24), (8, 16), (8, 8)]
+    V = 2
+    clouds, boxes = [], []
+    for (h, w) in grids:
+        ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+        sc = 32.0 / w
+        base = torch.stack([xs * 0.05 * sc, ys * 0.05 * sc, 0.2 * torch.sin(xs * 0.3)], -1).reshape(1, 1, h * w, 3)
+        x = torch.zeros(B, V * h * w, 4)
+        x[..., :3] = (base + torch.rand(B, V, h * w, 3, generator=g) * 0.02).reshape(B, V * h * w, 3)
+        xg = G(x)
+        bx = torch.empty(B, (V * h * w + 63) // 64, 8, device=DEV)
+        hip.tile_aabb(xg, V * h * w, B, bx, (w, h))
+        clouds.append(xg)
+        boxes.append(bx)
+    q = G((torch.rand(M, B, 3, generator=g) * torch.tensor([1.6, 0.8, 0.3])))
+    nsegs = [2, 1, 1]
+
+    def per_level(seeds):
+        out = []
+        for l, (h, w) in enumerate(grids):
+            P = V * h * w
+            keys = torch.empty(M * B * nsegs[l] * K, device=DEV, dtype=torch.int64)
+            kw = dict(seed_idx=seeds[l], seed_k=K) if seeds else {}
+            hip.knn_scan(clouds[l], P, q, M, B, 0, 1, B, K, nsegs[l], keys, box=boxes[l], grid=(w, h), **kw)
+            idx = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
+            hip.knn_merge(keys, M, B, K, nsegs[l], P, idx)
+            out.append(idx)
+        return out
+
+    def one_launch(seeds):
+        lv = []
+        for l, (h, w) in enumerate(grids):
+            P = V * h * w
+            lv.append(dict(xyz=clouds[l], P=P, keys=torch.empty(M * B * nsegs[l] * K, device=DEV, dtype=torch.int64), nseg=nsegs[l],
+                           seed_idx=seeds[l] if seeds else None, box=boxes[l], grid=(w, h),
+                           idx_out=torch.empty(M, B, K, device=DEV, dtype=torch.int32)))
+        hip.knn_scan_levels(lv, q, M, B, 0, 1, B, K, seed_k=K if seeds else 0)
+        hip.knn_merge_levels(lv, M, B, K)
+        return [d["idx_out"] for d in lv]
+
+    ref = per_level(None)
+    got = one_launch(None)
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    q += 0.004
+    ref2, got2 = per_level(ref), one_launch([r.clone() for r in ref])
+    torch.cuda.synchronize()
+    for a, b in zip(ref2, got2):
+        assert torch.equal(a, b)
+
+
 def test_corr_all_levels_one_launch(hip):
     g = torch.Generator().manual_seed(12)
     B, M, K, C = 2, 30, 16, 128
