@@ -167,7 +167,9 @@ int mvt_instnorm_stats(const void* x, int ldx, double* partial, float* mean_rstd
                        int io_flags /* MVT_IO_IN_BF16: x is bf16 */, void* stream);
 /* y = relu((x-mean)*rstd)                                  (skip == NULL)
  * y = relu(skip' + relu((x-mean)*rstd)), skip' = skip or (skip-mean_s)*rstd_s when skip_stats
- * is given (ResidualBlock.forward, blocks.py:119-128).  y may alias x. */
+ * is given (ResidualBlock.forward, blocks.py:119-128); with MVT_APPLY_SKIP_RELU in io_flags skip' = relu((skip-mean_s)*rstd_s),
+ * i.e. the skip tensor is itself a raw conv output whose norm + ReLU was never materialised (the stem).  y may alias x. */
+#define MVT_APPLY_SKIP_RELU 4
 int mvt_instnorm_apply(const void* x, const float* mean_rstd, const void* skip, const float* skip_stats, void* y,
                        int n, long long HW, int C, int io_flags /* 0, or IN|OUT: x, skip and y are all bf16 */, void* stream);
 

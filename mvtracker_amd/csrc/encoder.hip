@@ -136,7 +136,7 @@ __global__ __launch_bounds__(1024) void instnorm_finish_slots_kernel(const float
 
 __global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ st, const float* __restrict__ skip,
                                       const float* __restrict__ skst, float* __restrict__ y, long long HW, int C, long long total4,
-                                      int bf) {
+                                      int bf, int skip_relu) {
   const int cq = C / 4;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     int q = (int)(i % cq);
@@ -152,6 +152,10 @@ __global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* 
         const float* ks = skst + (img * C + q * 4) * 2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) k[e] = (k[e] - ks[e * 2]) * ks[e * 2 + 1];
+        if (skip_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) k[e] = fmaxf(k[e], 0.0f);
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fmaxf(k[e] + o[e], 0.0f);
@@ -235,11 +239,14 @@ extern "C" int mvt_instnorm_apply(const void* x, const float* mean_rstd, const v
                                   int n, long long HW, int C, int io_flags, void* stream) {
   MVT_REQUIRE(x && mean_rstd && y && n > 0 && HW > 0 && C > 0 && C % 4 == 0);
   const int both = MVT_IO_IN_BF16 | MVT_IO_OUT_BF16;
+  const int skip_relu = io_flags & MVT_APPLY_SKIP_RELU ? 1 : 0;
+  io_flags &= ~MVT_APPLY_SKIP_RELU;
   MVT_REQUIRE(io_flags == 0 || io_flags == both);  // x, skip and y share one element type
+  MVT_REQUIRE(!skip_relu || skip_stats);
   MVT_REQUIRE(skip || !skip_stats);
   long long total4 = (long long)n * HW * (C / 4);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, mvt_stream(stream), (const float*)x, mean_rstd,
-                     (const float*)skip, skip_stats, (float*)y, HW, C, total4, io_flags ? 1 : 0);
+                     (const float*)skip, skip_stats, (float*)y, HW, C, total4, io_flags ? 1 : 0, skip_relu);
   return mvt_launch_status();
 }
 

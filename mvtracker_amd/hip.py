@@ -206,9 +206,10 @@ def instnorm_stats(x, ldx, partial, mean_rstd, n, HW, Cc):
     _call("mvt_instnorm_stats", _ptr(x), ldx, _ptr(partial), _ptr(mean_rstd), n, HW, Cc, _io(x), _stream())
 
 
-def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc):
+def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc, skip_relu=False):
     assert y.dtype == x.dtype and (skip is None or skip.dtype == x.dtype)
-    _call("mvt_instnorm_apply", _ptr(x), _ptr(mean_rstd), _ptr(skip), _ptr(skip_stats), _ptr(y), n, HW, Cc, _io(x, y), _stream())
+    _call("mvt_instnorm_apply", _ptr(x), _ptr(mean_rstd), _ptr(skip), _ptr(skip_stats), _ptr(y), n, HW, Cc,
+          _io(x, y) | (4 if skip_relu else 0), _stream())
 
 
 def resize_bilinear_ac(src, dst, n, Hs, Ws, Cc, Hd, Wd, ldd, c_off):

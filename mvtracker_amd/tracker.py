@@ -297,18 +297,21 @@ class MVTracker(nn.Module):
         """Element type of the encoder's intermediate activations: bf16 in bf16 mode (HBM-bound layers, bf16 MFMA operands)."""
         return torch.bfloat16 if (self.bf16_activations and self.precision == "bf16") else torch.float32
 
-    def _inorm(self, x, n, HW, C, skip=None, skip_stats=None, apply=True, st=None):
+    def _inorm(self, x, n, HW, C, skip=None, skip_stats=None, apply=True, st=None, skip_relu=False):
         if st is None:
             partial = torch.empty(n * hip.IN_SLABS * C * 2, device=x.device, dtype=torch.float64)
             st = torch.empty(n, C, 2, device=x.device)
             hip.instnorm_stats(x, C, partial, st, n, HW, C)
         if apply:
-            hip.instnorm_apply(x, st, skip, skip_stats, x, n, HW, C)
+            hip.instnorm_apply(x, st, skip, skip_stats, x, n, HW, C, skip_relu=skip_relu)
         return st
 
-    def _res_block(self, pk, p, x, n, H, W, cin, cout, stride):
+    def _res_block(self, pk, p, x, n, H, W, cin, cout, stride, x_stats=None):
+        """ResidualBlock (blocks.py:84-128).  ``x_stats``: x is a raw conv output whose InstanceNorm + ReLU was never
+        materialised (the stem): conv1 normalises while it loads and the skip connection is normalised in the final pass."""
         fuse_in = self.fuse_norm and isinstance(pk[p + ".conv2"][0], tuple) and cout % 32 == 0
-        y, Ho, Wo, st1 = self._conv(pk, p + ".conv1", x, n, H, W, cin, cout, 3, stride, 1, stats=True)
+        assert x_stats is None or (stride == 1 and (p + ".downsample.0") not in pk)
+        y, Ho, Wo, st1 = self._conv(pk, p + ".conv1", x, n, H, W, cin, cout, 3, stride, 1, stats=True, in_stats=x_stats)
         if not fuse_in:  # otherwise conv2 normalises while it loads its patch
             self._inorm(y, n, Ho * Wo, cout, st=st1)
         y2, _, _, st2 = self._conv(pk, p + ".conv2", y, n, Ho, Wo, cout, cout, 3, 1, 1, in_stats=st1 if fuse_in else None,
@@ -317,7 +320,7 @@ class MVTracker(nn.Module):
             d, _, _, dst = self._conv(pk, p + ".downsample.0", x, n, H, W, cin, cout, 1, stride, 0, stats=True)
             self._inorm(y2, n, Ho * Wo, cout, skip=d, skip_stats=dst, st=st2)
         else:
-            self._inorm(y2, n, Ho * Wo, cout, skip=x, st=st2)
+            self._inorm(y2, n, Ho * Wo, cout, skip=x, skip_stats=x_stats, skip_relu=x_stats is not None, st=st2)
         return y2, Ho, Wo
 
     def _encode(self, pk, x4, n, H, W, out_rows):
@@ -325,17 +328,23 @@ class MVTracker(nn.Module):
         C = self.latent_dim
         hs, ws = H // self.stride, W // self.stride
         x, h, w, st = self._conv(pk, "fnet.conv1", x4, n, H, W, 4, 64, 7, 2, 3, stats=True)
-        self._inorm(x, n, h * w, 64, st=st)
+        lazy_stem = self.fuse_norm and self.precision == "bf16"  # relu(IN(stem)) is applied by its two consumers instead
+        if not lazy_stem:
+            self._inorm(x, n, h * w, 64, st=st)
         cat = torch.empty(n, hs, ws, 416, device=x4.device, dtype=self._act_dtype(pk))
         cin, off = 64, 0
         for li, (cout, stride) in enumerate(((64, 1), (96, 2), (128, 2), (128, 2)), start=1):
-            x, h, w = self._res_block(pk, f"fnet.layer{li}.0", x, n, h, w, cin, cout, stride)
+            x, h, w = self._res_block(pk, f"fnet.layer{li}.0", x, n, h, w, cin, cout, stride, x_stats=st if (li == 1 and lazy_stem) else None)
             x, h, w = self._res_block(pk, f"fnet.layer{li}.1", x, n, h, w, cout, cout, 1)
             hip.resize_bilinear_ac(x, cat, n, h, w, cout, hs, ws, 416, off)
             cin, off = cout, off + cout
         y, _, _, st = self._conv(pk, "fnet.conv2", cat, n, hs, ws, 416, 2 * C, 3, 1, 1, stats=True)
-        self._inorm(y, n, hs * ws, 2 * C, st=st)
-        self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C)
+        if self.fuse_norm and self.precision == "bf16" and (2 * C) % 32 == 0:
+            # the 1x1 output conv normalises while it loads (row-tile kernel): no separate InstanceNorm pass
+            self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C, in_stats=st)
+        else:
+            self._inorm(y, n, hs * ws, 2 * C, st=st)
+            self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C)
 
     def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16, out=None):
         """rgbs (V,T,3,H,W) in [0,255] -> level-0 features (T,V,H/4,W/4,C); frames outside [t0,t1) are left zero

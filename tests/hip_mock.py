@@ -181,7 +181,7 @@ def instnorm_stats(x, ldx, partial, mean_rstd, n, HW, Cc):
     st[..., 1] = (1.0 / torch.sqrt(var.clamp_min(0) + 1e-5)).float()
 
 
-def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc):
+def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc, skip_relu=False):
     xv = torch.as_strided(x, (n, HW, Cc), (HW * Cc, Cc, 1)).float()
     st = torch.as_strided(mean_rstd, (n, 1, Cc, 2), (Cc * 2, 0, 2, 1))
     o = F.relu((xv - st[..., 0]) * st[..., 1])
@@ -190,6 +190,8 @@ def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc):
         if skip_stats is not None:
             ks = torch.as_strided(skip_stats, (n, 1, Cc, 2), (Cc * 2, 0, 2, 1))
             k = (k - ks[..., 0]) * ks[..., 1]
+            if skip_relu:
+                k = F.relu(k)
         o = F.relu(k + o)
     torch.as_strided(y, (n, HW, Cc), (HW * Cc, Cc, 1)).copy_(o)
 

@@ -424,6 +424,8 @@ def test_instnorm(hip, C, HW):
     hip.instnorm_apply(xg, st, G(skip), st, y, n, HW, C)  # skip normalised with (here: the same) statistics
     sk = (skip.double() - st.cpu()[:, None, :, 0].double()) * st.cpu()[:, None, :, 1].double()
     assert (y.cpu().double() - F.relu(sk + ref)).abs().max() < 1e-4
+    hip.instnorm_apply(xg, st, G(skip), st, y, n, HW, C, skip_relu=True)  # the skip is a raw conv output: relu(IN(skip))
+    assert (y.cpu().double() - F.relu(F.relu(sk) + ref)).abs().max() < 1e-4
 
 
 @pytest.mark.parametrize("Hs,Ws,Hd,Wd", [(32, 48, 16, 24), (8, 12, 16, 24), (16, 24, 16, 24), (4, 6, 16, 24)])
