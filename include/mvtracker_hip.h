@@ -82,8 +82,8 @@ int mvt_conv2d(const float* in, const float* wt, const float* bias, float* out, 
 /* hi[i] = bf16(src[i]) (round to nearest even), lo[i] = bf16(src[i] - hi[i]) (lo optional); n % 4 == 0. */
 int mvt_split_bf16(const float* src, unsigned short* hi, unsigned short* lo, long long n, void* stream);
 int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const unsigned short* w_lo, int ldw,
-                  const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int act,
-                  void* stream);
+                  const float* bias, const float* R, int ldr, void* C, int ldc, int M, int N, int K, int act,
+                  int io_flags /* MVT_IO_OUT_BF16: C is a bf16 tensor */, void* stream);
 /* InstanceNorm fusion of the bf16 convolutions (saves the separate statistics pass and the normalise pass between
  * the two convs of a ResidualBlock, blocks.py:119-122):
  *   in_stats    [n][Cin][2] (mean, rstd) or NULL: the input is read as relu((x - mean) * rstd) (3x3 stride-1 pad-1 only);
@@ -139,14 +139,16 @@ typedef struct mvt_block_next {
   const float* b;          /* [N] */
   const float* lnw;        /* LayerNorm affine [256] or NULL (both) */
   const float* lnb;
-  float* y;                /* [M][ldy] */
+  float* y;                /* [M][ldy] fp32, or bf16 when y_bf16 */
   int ldw, N, ldy;
   float eps;
   long long row_lo, row_hi; /* the projection is evaluated for rows [row_lo, row_hi) only (y is indexed by the global row);
                                row_hi == 0: every row */
+  int y_bf16;               /* 1: y is a bf16 tensor (the q / k / v operands of mvt_attention_bf16) */
 } mvt_block_next;
 #define MVT_BLOCK_MAX_NEXT 3
-int mvt_block_fused_bf16(float* x, int ldx, const float* att, int ldatt, int Ko, const unsigned short* wo, int ldwo,
+int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 when att_bf16 */, int att_bf16, int ldatt, int Ko,
+                         const unsigned short* wo, int ldwo,
                          const float* bo, const unsigned short* w1, int ldw1, const float* b1, const unsigned short* w2,
                          int ldw2, const float* b2, int H, const mvt_block_next* next, int n_next, long long M, int C,
                          void* stream);
@@ -298,9 +300,10 @@ int mvt_attention(const float* q, int ldq, long long q_gs, long long q_is, const
                   int heads, int dh, void* stream);
 /* Same contract on the bf16 matrix cores (flash-style, scores never leave registers; dh == 48): q/k/v are rounded to
  * bf16, accumulation and softmax in fp32. */
-int mvt_attention_bf16(const float* q, int ldq, long long q_gs, long long q_is, const float* k, const float* v,
-                       int ldkv, long long k_gs, long long k_is, float* o, int ldo, int groups, int nq, int nk,
-                       int heads, int dh, void* stream);
+int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, const void* k, const void* v,
+                       int ldkv, long long k_gs, long long k_is, void* o, int ldo, int groups, int nq, int nk,
+                       int heads, int dh, int io_flags /* MVT_IO_IN_BF16: q, k, v are bf16 tensors; MVT_IO_OUT_BF16: o is */,
+                       void* stream);
 /* x[(n*S+s)*ld + 0:C] = v[n][0:C] for all s  (virtual-token broadcast, blocks.py:458-459). */
 int mvt_broadcast_rows(const float* v, float* x, int ld, int n, int S, int C, void* stream);
 

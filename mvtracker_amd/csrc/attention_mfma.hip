@@ -21,7 +21,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int DH = 48;
 constexpr int LDV = 40;  // bf16 row stride of the V^T image: 32 keys + 8 pad (80 B)
 
-__device__ __forceinline__ bf16x8 cvt8(const float* p) {
+// eight consecutive elements at element offset `off` of a fp32 or bf16 tensor, as bf16
+__device__ __forceinline__ bf16x8 load8(const float* base, long long off, int bf) {
+  if (bf) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(base) + off));
+  const float* p = base + off;
   const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
   const bf16x4 x = __builtin_convertvector(a, bf16x4), y = __builtin_convertvector(b, bf16x4);
   bf16x8 o;
@@ -36,7 +39,8 @@ __device__ __forceinline__ bf16x8 cvt8(const float* p) {
 template <int KS>
 __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel(
     const float* __restrict__ q, int ldq, long long q_gs, long long q_is, const float* __restrict__ k, const float* __restrict__ v,
-    int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads) {
+    int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads, int bf_in,
+    int bf_out) {
   constexpr int NW = KS == 1 ? 4 : KS;
   constexpr int VT = 64 * LDV;                              // bf16 elements of one wave's V^T image (64 d rows)
   constexpr int MERGE = KS > 1 ? (KS - 1) * 64 * 68 : 0;    // floats: per lane m[2], l[2], 64 accumulators
@@ -62,10 +66,10 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     const int qi = qc * 64 + mb * 32 + r;
-    const float* qp = q + (g * q_gs + (long long)(qi < nq ? qi : nq - 1) * q_is) * ldq + hd * DH;
+    const long long qo = (g * q_gs + (long long)(qi < nq ? qi : nq - 1) * q_is) * ldq + hd * DH;
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 8 * h), b = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 8 * h + 4);
+      f32x4 a = load_act4(q, qo + ks * 16 + 8 * h, bf_in), b = load_act4(q, qo + ks * 16 + 8 * h + 4, bf_in);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         a[e] *= scale;
@@ -99,27 +103,26 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
   const int per = (nkb + KS - 1) / KS;
   const int kb0 = KS == 1 ? 0 : wave * per;
   const int kb1 = KS == 1 ? nkb : (kb0 + per < nkb ? kb0 + per : nkb);
-  const float* kbase = k + (g * k_gs) * ldkv + hd * DH;
-  const float* vbase = v + (g * k_gs) * ldkv + hd * DH;
+  const long long kvbase = (g * k_gs) * ldkv + hd * DH;  // element offset (fp32 or bf16 tensors)
   const long long kstep = k_is * ldkv;
 
 #pragma unroll 1
   for (int kb = kb0; kb < kb1; ++kb) {
     // ---- K block: A fragments (key row r of this block, k = d)
     const int key = kb * 32 + r;
-    const float* kp = kbase + (long long)(key < nk ? key : nk - 1) * kstep;
+    const long long ko = kvbase + (long long)(key < nk ? key : nk - 1) * kstep;
     bf16x8 kf[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) kf[ks] = cvt8(kp + ks * 16 + 8 * h);
+    for (int ks = 0; ks < 3; ++ks) kf[ks] = load8(k, ko + ks * 16 + 8 * h, bf_in);
     // ---- V block -> transposed LDS image vt[d][key]: lane handles key (lane & 31), d range 24 * (lane >> 5) .. +23
     {
-      const float* vp = vbase + (long long)(key < nk ? key : nk - 1) * kstep + 24 * h;
+      const long long vo = ko + 24 * h;
       // (the image is written as 16-bit elements and read back as 32-bit vectors: a wavefront-scope fence keeps the
       //  compiler's type-based alias analysis from reordering the two)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(vp + 4 * i);
+        f32x4 a = load_act4(v, vo + 4 * i, bf_in);
         if (key >= nk) a = (f32x4){0.f, 0.f, 0.f, 0.f};
         // (16-bit element extraction from the packed bf16 vector is done on the 32-bit words: hipcc 7.2 emits
         //  ds_write_b16 of the same low half for every element of `b[e]` otherwise)
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
     const float inv = 1.0f / lt;
     const int qi = qc * 64 + mb * 32 + r;
     if (qi >= nq) continue;
-    float* op = o + (g * q_gs + (long long)qi * q_is) * ldo + hd * DH;
+    const long long oo = (g * q_gs + (long long)qi * q_is) * ldo + hd * DH;
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
 #pragma unroll
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
           f32x4 t;
 #pragma unroll
           for (int e = 0; e < 4; ++e) t[e] = oacc[mb][db][4 * gq + e] * inv;
-          *reinterpret_cast<f32x4*>(op + d) = t;
+          store_act4(o, oo + d, t, bf_out);
         }
       }
     }
@@ -248,16 +251,20 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
 
 }  // namespace
 
-extern "C" int mvt_attention_bf16(const float* q, int ldq, long long q_gs, long long q_is, const float* k, const float* v,
-                                  int ldkv, long long k_gs, long long k_is, float* o, int ldo, int groups, int nq, int nk,
-                                  int heads, int dh, void* stream) {
+extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, const void* k, const void* v,
+                                  int ldkv, long long k_gs, long long k_is, void* o, int ldo, int groups, int nq, int nk,
+                                  int heads, int dh, int io_flags, void* stream) {
+  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16)) == 0);
+  const int bf_in = io_flags & MVT_IO_IN_BF16 ? 1 : 0, bf_out = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
+  MVT_REQUIRE(!bf_in || (ldq % 8 == 0 && ldkv % 8 == 0));  // 16-B aligned rows
+  MVT_REQUIRE(!bf_out || ldo % 8 == 0);
   MVT_REQUIRE(q && k && v && o && groups > 0 && nq > 0 && nk > 0 && heads > 0 && dh == DH);
   MVT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= heads * dh && ldkv >= heads * dh && ldo >= heads * dh);
   MVT_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 16 == 0));
   const long long nchunk = (long long)groups * heads * ((nq + 63) / 64);
 #define LAUNCH(KS, BLOCKS, THREADS)                                                                                        \
-  hipLaunchKernelGGL((attention_mfma_kernel<KS>), dim3((unsigned)(BLOCKS)), dim3(THREADS), 0, mvt_stream(stream), q, ldq, q_gs, \
-                     q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads)
+  hipLaunchKernelGGL((attention_mfma_kernel<KS>), dim3((unsigned)(BLOCKS)), dim3(THREADS), 0, mvt_stream(stream), (const float*)q, ldq, q_gs, \
+                     q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out)
   if (nk >= 512 && nchunk < 1024) {
     LAUNCH(4, nchunk, 256);
   } else {

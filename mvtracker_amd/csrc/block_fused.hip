@@ -58,6 +58,7 @@ struct BlockArgs {
   int ldw1, ldw2, H;
   mvt_block_next next[MVT_BLOCK_MAX_NEXT];    // follow-up projections of LayerNorm(x)
   int n_next;
+  int att_bf16;              // att is a bf16 tensor
   long long M;
 };
 
@@ -241,10 +242,16 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     for (int f = t; f < BM * q4; f += NT) {
       const int row = f / q4, c = (f - row * q4) * 4;
       const long long m = m0 + row;
-      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) a = *reinterpret_cast<const f32x4*>(p.att + m * (long long)p.ldatt + c);
-      const bf16x4 b = __builtin_convertvector(a, bf16x4);
-      *reinterpret_cast<u32x2*>(&As[row * LDA + c]) = __builtin_bit_cast(u32x2, b);
+      u32x2 w = (u32x2){0u, 0u};
+      if (m < p.M) {
+        if (p.att_bf16) {
+          w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.att) + m * (long long)p.ldatt + c);
+        } else {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p.att + m * (long long)p.ldatt + c);
+          w = __builtin_bit_cast(u32x2, __builtin_convertvector(a, bf16x4));
+        }
+      }
+      *reinterpret_cast<u32x2*>(&As[row * LDA + c]) = w;
     }
     __syncthreads();
     gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);
@@ -381,11 +388,11 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = acc[mb][4 * g + e] + b1s[n + e];
-            *reinterpret_cast<f32x4*>(nx.y + m * (long long)nx.ldy + n) = o;
+            store_act4(nx.y, m * (long long)nx.ldy + n, o, nx.y_bf16);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (n + e < nx.N) nx.y[m * (long long)nx.ldy + n + e] = acc[mb][4 * g + e] + b1s[n + e];
+              if (n + e < nx.N) store_act(nx.y, m * (long long)nx.ldy + n + e, acc[mb][4 * g + e] + b1s[n + e], nx.y_bf16);
           }
         }
       }
@@ -420,7 +427,7 @@ extern "C" int mvt_pack_frag_bf16(const unsigned short* w, int ld, int N, int K,
   return mvt_launch_status();
 }
 
-extern "C" int mvt_block_fused_bf16(float* x, int ldx, const float* att, int ldatt, int Ko, const unsigned short* wo, int ldwo,
+extern "C" int mvt_block_fused_bf16(float* x, int ldx, const void* att, int att_bf16, int ldatt, int Ko, const unsigned short* wo, int ldwo,
                                     const float* bo, const unsigned short* w1, int ldw1, const float* b1, const unsigned short* w2,
                                     int ldw2, const float* b2, int H, const mvt_block_next* next, int n_next, long long M, int Cc,
                                     void* stream) {
@@ -431,11 +438,12 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const float* att, int lda
   MVT_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)att % 16 == 0) && ((uintptr_t)wo % 16 == 0) && ((uintptr_t)w1 % 16 == 0) &&
               ((uintptr_t)w2 % 16 == 0));
   BlockArgs a{};
-  a.x = x; a.ldx = ldx; a.att = att; a.ldatt = ldatt; a.Ko = Ko; a.wo = wo; a.bo = bo; a.ldwo = ldwo;
+  a.x = x; a.ldx = ldx; a.att = (const float*)att; a.att_bf16 = att_bf16 ? 1 : 0; a.ldatt = ldatt; a.Ko = Ko; a.wo = wo; a.bo = bo; a.ldwo = ldwo;
   a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.ldw1 = ldw1; a.ldw2 = ldw2; a.H = H; a.M = M; a.n_next = n_next;
   for (int q = 0; q < n_next; ++q) {
     const mvt_block_next& nx = next[q];
     MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
+    MVT_REQUIRE(nx.y_bf16 == 0 || nx.y_bf16 == 1);
     MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
     MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo));
     a.next[q] = nx;

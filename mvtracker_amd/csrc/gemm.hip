@@ -813,15 +813,16 @@ extern "C" int mvt_split_bf16(const float* src, unsigned short* hi, unsigned sho
 }
 
 extern "C" int mvt_gemm_bf16(const float* A, int lda, const unsigned short* Whi, const unsigned short* Wlo, int ldw,
-                             const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int act,
-                             void* stream) {
+                             const float* bias, const float* R, int ldr, void* C, int ldc, int M, int N, int K, int act,
+                             int io_flags, void* stream) {
   MVT_REQUIRE(A && Whi && C && M > 0 && N > 0 && K > 0);
   MVT_REQUIRE(lda % 4 == 0 && lda >= ((K + 3) & ~3));
   MVT_REQUIRE(ldw % 64 == 0 && ldw >= ((K + 63) & ~63) && ldc >= N && (!R || ldr >= N));
-  MVT_REQUIRE(act >= 0 && act <= 3);
+  MVT_REQUIRE(act >= 0 && act <= 3 && (io_flags & ~MVT_IO_OUT_BF16) == 0);
   MVT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)Whi % 8 == 0) && ((uintptr_t)Wlo % 8 == 0));
   GemmArgs a{};
-  a.A = A; a.Whi = Whi; a.Wlo = Wlo; a.bias = bias; a.R = R; a.C = C;
+  a.A = A; a.Whi = Whi; a.Wlo = Wlo; a.bias = bias; a.R = R; a.C = (float*)C;
+  a.c_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.act = act;
   a.mode = 0;
   a.nk = (K + BKB - 1) / BKB;

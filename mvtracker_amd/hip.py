@@ -30,13 +30,13 @@ SIGNATURES = {
     "mvt_gemm": [P, I, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "mvt_split_bf16": [P, P, P, LL, P],
-    "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, P],
+    "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P],
     "mvt_conv2d_stat_slots": [I, I, I, I, I, I, I, I],
     "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P],
     "mvt_instnorm_finish_slots": [P, I, P, I, LL, I, P],
     "mvt_ln_gemm_bf16": [P, I, P, P, F, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_pack_frag_bf16": [P, I, I, I, P, P],
-    "mvt_block_fused_bf16": [P, I, P, I, I, P, I, P, P, I, P, P, I, P, I, P, I, LL, I, P],
+    "mvt_block_fused_bf16": [P, I, P, I, I, I, P, I, P, P, I, P, P, I, P, I, P, I, LL, I, P],
     "mvt_mlp_fused_bf16": [P, I, P, I, P, P, I, P, LL, I, I, F, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
@@ -61,7 +61,7 @@ SIGNATURES = {
     "mvt_rowdot": [P, I, P, P, P, LL, I, P],
     "mvt_layernorm": [P, I, P, P, P, I, LL, I, F, P],
     "mvt_attention": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, P],
-    "mvt_attention_bf16": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, P],
+    "mvt_attention_bf16": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, I, P],
     "mvt_broadcast_rows": [P, P, I, I, I, I, P],
 }
 _RET = {"mvt_build_arch": C.c_char_p}
@@ -142,7 +142,7 @@ def split_bf16(src, hi, lo, n):
 
 def gemm_bf16(A, lda, Whi, Wlo, ldw, bias, R, ldr, Cm, ldc, M, N, K, act=ACT_NONE):
     _call("mvt_gemm_bf16", _ptr(A), lda, _ptr(Whi), _ptr(Wlo), ldw, _ptr(bias), _ptr(R), ldr, _ptr(Cm), ldc, M, N, K, act,
-          _stream())
+          _io(None, Cm), _stream())
 
 
 def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False) -> int:
@@ -173,7 +173,7 @@ class BlockNext(C.Structure):
     """mvt_block_next of include/mvtracker_hip.h."""
     _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("lnw", C.c_void_p), ("lnb", C.c_void_p), ("y", C.c_void_p),
                 ("ldw", C.c_int), ("N", C.c_int), ("ldy", C.c_int), ("eps", C.c_float), ("row_lo", C.c_longlong),
-                ("row_hi", C.c_longlong)]
+                ("row_hi", C.c_longlong), ("y_bf16", C.c_int)]
 
 
 BLOCK_MAX_NEXT = 3
@@ -185,8 +185,8 @@ def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw
     arr = (BlockNext * max(1, len(nexts)))()
     for i, nx in enumerate(nexts):
         arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],
-                           nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)))
-    _call("mvt_block_fused_bf16", _ptr(x), ldx, _ptr(att), ldatt, Ko, _ptr(wo), ldwo, _ptr(bo), _ptr(w1), ldw1, _ptr(b1), _ptr(w2),
+                           nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)), 1 if nx["y"].dtype == torch.bfloat16 else 0)
+    _call("mvt_block_fused_bf16", _ptr(x), ldx, _ptr(att), 1 if (att is not None and att.dtype == torch.bfloat16) else 0, ldatt, Ko, _ptr(wo), ldwo, _ptr(bo), _ptr(w1), ldw1, _ptr(b1), _ptr(w2),
           ldw2, _ptr(b2), H, C.cast(arr, C.c_void_p), len(nexts), M, Cc, _stream())
 
 
@@ -321,8 +321,9 @@ def attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk
 
 
 def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
+    assert q.dtype == k.dtype == v.dtype
     _call("mvt_attention_bf16", _ptr(q), ldq, q_gs, q_is, _ptr(k), _ptr(v), ldkv, k_gs, k_is, _ptr(o), ldo, groups, nq, nk, heads,
-          dh, _stream())
+          dh, _io(q, o), _stream())
 
 
 def broadcast_rows(v, x, ld, n, S, Cc):

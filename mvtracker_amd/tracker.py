@@ -109,6 +109,7 @@ class MVTracker(nn.Module):
         self.mfma_attention = True
         self.overlap_encoder = os.environ.get("MVT_OVERLAP", "1") != "0"  # encode later frames on a second stream
         self._side = {}
+        self.bf16_tokens = os.environ.get("MVT_BF16_TOK", "1") != "0"  # bf16 mode: q/k/v and attention outputs stored as bf16
         self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
@@ -531,17 +532,22 @@ class MVTracker(nn.Module):
         dev = x.device
         Mp, Mv = n * S, nv * S
         M = Mp + Mv
+        space_mfma = self.mfma_attention and dh == 48
         tok = torch.empty(M, h, device=dev)
         xn = torch.empty(M, h, device=dev)
         # q|k|v of the time / virtual-self attention; cross attention: q in [:, :inner], k|v in [:, inner:].  Two buffers,
         # swapped every layer: the next layer's time q|k|v is projected (by the block epilogues) while this layer's
         # cross-attention k|v are still being read.
-        qkv = torch.empty(M, 3 * inner, device=dev)
-        qkv_nx = torch.empty(M, 3 * inner, device=dev)
-        qp = torch.empty(Mp, inner, device=dev)       # point <- virtual queries (computed right after the time block)
-        att = torch.empty(M, inner, device=dev)
+        # (bf16 tensors in bf16 mode: they only ever feed bf16 MFMA operands, and the block / attention kernels are bound
+        #  by exactly this traffic)
+        tdt = torch.bfloat16 if (self.bf16_tokens and space_mfma) else torch.float32
+        qkv = torch.empty(M, 3 * inner, device=dev, dtype=tdt)
+        qkv_nx = torch.empty(M, 3 * inner, device=dev, dtype=tdt)
+        qp = torch.empty(Mp, inner, device=dev, dtype=tdt)       # point <- virtual queries (computed right after the time block)
+        att = torch.empty(M, inner, device=dev, dtype=tdt)
         u = "updateformer."
-        space_attn = hip.attention_bf16 if (self.mfma_attention and dh == 48) else hip.attention
+        space_attn = hip.attention_bf16 if space_mfma else hip.attention
+        time_attn = hip.attention_bf16 if space_mfma else hip.attention  # 12 keys pad to one 32-key MFMA block: still 1.4x the VALU kernel
         self._lin(pk, u + "input_transform", x, ldx, Mp, tok, h)
         hip.broadcast_rows(pk["virtual"], tok[Mp:], h, nv, S, h)
         pt, vt = tok[:Mp], tok[Mp:]
@@ -552,7 +558,7 @@ class MVTracker(nn.Module):
             last = i + 1 == self.depth
             nxt_qkv = f"{u}time_blocks.{i + 1}.attn.qkv"
             # time attention, then the rest of the time block; its epilogue already projects what the space blocks need
-            hip.attention(qkv, 3 * inner, S, 1, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, S, 1, att, inner, n + nv, S, S, H, dh)
+            time_attn(qkv, 3 * inner, S, 1, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, S, 1, att, inner, n + nv, S, S, H, dh)
             # (one launch over point and virtual rows: same weights, the follow-up projections differ by row range)
             self._fused_block(pk, tb, "attn", tok, M, att,
                               [self._next(pk, v2p + ".cross_attn.to_kv", qkv[:, inner:], 3 * inner, pk[v2p + ".norm_context"], 1e-5,

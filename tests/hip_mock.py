@@ -89,7 +89,7 @@ def _unfrag(wf, N, K):
 def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw2, b2, H, nexts, M, Cc):
     xv = _v(x, M, Cc, ldx)
     if att is not None:
-        xv += _bf(_v(att, M, Ko, ldatt)) @ _unfrag(wo, Cc, Ko).t() + bo[:Cc]
+        xv += _bf(_v(att, M, Ko, ldatt).float()) @ _unfrag(wo, Cc, Ko).t() + bo[:Cc]
     hdn = F.gelu(_bf(F.layer_norm(xv, (Cc,), None, None, 1e-6)) @ _unfrag(w1, H, Cc).t() + b1[:H], approximate="tanh")
     xv += _bf(hdn) @ _unfrag(w2, Cc, H).t() + b2[:Cc]
     for nx in nexts:
@@ -97,7 +97,7 @@ def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw
         a = _bf(F.layer_norm(xv, (Cc,), nx.get("lnw"), nx.get("lnb"), nx["eps"]))
         lo, hi = nx.get("rows", (0, 0))
         hi = hi or M
-        _v(nx["y"], hi, nx["N"], nx["ldy"])[lo:hi] = (a @ Wn.t() + nx["b"][:nx["N"]])[lo:hi]
+        _v(nx["y"], hi, nx["N"], nx["ldy"])[lo:hi] = (a @ Wn.t() + nx["b"][:nx["N"]])[lo:hi].to(nx["y"].dtype)
 
 
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
@@ -363,9 +363,9 @@ def layernorm(x, ldx, w, b, y, ldy, rows, Cc, eps):
 
 
 def attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
-    Q = torch.as_strided(q, (groups, nq, heads, dh), (q_gs * ldq, q_is * ldq, dh, 1)).permute(0, 2, 1, 3)
-    Kt = torch.as_strided(k, (groups, nk, heads, dh), (k_gs * ldkv, k_is * ldkv, dh, 1)).permute(0, 2, 1, 3)
-    Vt = torch.as_strided(v, (groups, nk, heads, dh), (k_gs * ldkv, k_is * ldkv, dh, 1)).permute(0, 2, 1, 3)
+    Q = torch.as_strided(q, (groups, nq, heads, dh), (q_gs * ldq, q_is * ldq, dh, 1)).permute(0, 2, 1, 3).float()
+    Kt = torch.as_strided(k, (groups, nk, heads, dh), (k_gs * ldkv, k_is * ldkv, dh, 1)).permute(0, 2, 1, 3).float()
+    Vt = torch.as_strided(v, (groups, nk, heads, dh), (k_gs * ldkv, k_is * ldkv, dh, 1)).permute(0, 2, 1, 3).float()
     y = F.scaled_dot_product_attention(Q, Kt, Vt).permute(0, 2, 1, 3)
     torch.as_strided(o, (groups, nq, heads, dh), (q_gs * ldo, q_is * ldo, dh, 1)).copy_(y)
 

@@ -815,6 +815,64 @@ def test_attention_bf16(hip, mode, n):
     assert (got - ref).abs().max() < 3e-2 and (got - ref).abs().mean() < 3e-3  # bf16 operands / probabilities
 
 
+def test_updater_bf16_token_tensors(hip):
+    """q/k/v, attention outputs and follow-up projections as bf16 tensors (bf16 mode) == the same kernels on fp32 tensors
+    holding the bf16 values, outputs rounded to nearest even; also the 12-key time attention on the MFMA kernel."""
+    g = torch.Generator().manual_seed(14)
+    n, nv, S, H, dh = 40, 64, 12, 6, 48
+    inner = H * dh
+    M = (n + nv) * S
+    Mp = n * S
+    qkv_b = torch.randn(M, 3 * inner, generator=g).to(torch.bfloat16)
+    qb, qf = G(qkv_b), G(qkv_b.float())
+    for args_of in (lambda t, o: (t, 3 * inner, S, 1, t[:, inner:], t[:, 2 * inner:], 3 * inner, S, 1, o, inner, n + nv, S, S, H, dh),        # time
+                    lambda t, o: (t[Mp:], 3 * inner, 1, S, t[:Mp, inner:], t[:Mp, 2 * inner:], 3 * inner, 1, S, o[Mp:], inner, S, nv, n, H, dh)):  # v2p
+        of = torch.zeros(M, inner, device=DEV)
+        ob = torch.zeros(M, inner, device=DEV, dtype=torch.bfloat16)
+        hip.attention_bf16(*args_of(qf, of))
+        hip.attention_bf16(*args_of(qb, ob))
+        torch.cuda.synchronize()
+        assert torch.equal(of.to(torch.bfloat16), ob)
+    # time attention against fp64 softmax attention
+    of = torch.zeros(M, inner, device=DEV)
+    hip.attention_bf16(qf, 3 * inner, S, 1, qf[:, inner:], qf[:, 2 * inner:], 3 * inner, S, 1, of, inner, n + nv, S, S, H, dh)
+    t = qkv_b.float().reshape(n + nv, S, 3, H, dh).permute(2, 0, 3, 1, 4).double()
+    ref = F.scaled_dot_product_attention(t[0], t[1], t[2]).permute(0, 2, 1, 3).reshape(M, inner)
+    assert (of.cpu().double() - ref).abs().max() < 3e-2
+    # fused block: bf16 att in, bf16 y out
+    C, Hd, Ko = 256, 1024, inner
+    x = torch.randn(M, C, generator=g)
+    att_b = torch.randn(M, Ko, generator=g).to(torch.bfloat16)
+
+    def hw(nn_, k):
+        w = torch.randn(nn_, k, generator=g) / math.sqrt(k)
+        hi = split(hip, G(pad_w(w)), False)[0]
+        fr = torch.empty((nn_ + 31) // 32 * 32 * k, device=DEV, dtype=torch.int16)
+        hip.pack_frag_bf16(hi, hi.shape[1], nn_, k, fr)
+        return fr
+
+    who, wh1, wh2, wn = hw(C, Ko), hw(Hd, C), hw(C, Hd), hw(3 * inner, C)
+    bo, b1, b2, bn = (G(torch.randn(k_, generator=g) * 0.1) for k_ in (C, Hd, C, 3 * inner))
+    outs = []
+    for att, ydt in ((G(att_b.float()), torch.float32), (G(att_b), torch.bfloat16)):
+        xg = G(x)
+        y = torch.zeros(M, 3 * inner, device=DEV, dtype=ydt)
+        hip.block_fused_bf16(xg, C, att, Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, Hd, b2, Hd,
+                             [dict(w=wn, ldw=C, b=bn, N=3 * inner, y=y, ldy=3 * inner, eps=1e-6)], M, C)
+        outs.append((xg, y))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1].to(torch.bfloat16), outs[1][1])
+    # plain GEMM with a bf16 output tensor
+    A = G(torch.randn(300, C, generator=g))
+    w = torch.randn(200, C, generator=g) / 16
+    hi = split(hip, G(pad_w(w)), False)[0]
+    cf, cb = torch.empty(300, 200, device=DEV), torch.empty(300, 200, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16(A, C, hi, None, hi.shape[1], None, None, 0, cf, 200, 300, 200, C)
+    hip.gemm_bf16(A, C, hi, None, hi.shape[1], None, None, 0, cb, 200, 300, 200, C)
+    torch.cuda.synchronize()
+    assert torch.equal(cf.to(torch.bfloat16), cb)
+
+
 def test_delta_split_rowdot_broadcast(hip):
     g = torch.Generator().manual_seed(9)
     rows, C = 500, 128
