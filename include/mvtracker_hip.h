@@ -151,6 +151,8 @@ int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 whe
                          const unsigned short* wo, int ldwo,
                          const float* bo, const unsigned short* w1, int ldw1, const float* b1, const unsigned short* w2,
                          int ldw2, const float* b2, int H, const mvt_block_next* next, int n_next, long long M, int C,
+                         float* workspace /* NULL, or (H/256 + 1) * M * C floats: lets small M (<= 2048 rows) run as two
+                                             launches cut over 4x more workgroups (deterministic partial sums) */,
                          void* stream);
 
 /* rgbs [V][T][3][H][W] (values 0..255) -> x [T_sel][V][H][W][4] = (2*(rgb/255)-1, 0) for frames

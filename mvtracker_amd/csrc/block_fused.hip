@@ -60,6 +60,7 @@ struct BlockArgs {
   int n_next;
   int att_bf16;              // att is a bf16 tensor
   long long M;
+  float* ws;                 // split path (small M): [M][C] x after the projection, then [H/256][M][C] partial MLP outputs
 };
 
 __device__ __forceinline__ bf16x8 ldg_frag(const unsigned short* p) {
@@ -213,7 +214,13 @@ __device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short
   __syncthreads();
 }
 
-template <int NMB>
+// MODE 0: the whole block in one workgroup per row tile.
+// MODE 1 / 2: the same block cut over more workgroups for the 768 virtual-track rows, where 24 row tiles each streaming
+// every weight through one CU were pure latency.  Pass 1 (grid.y = MLP chunk): projection + residual + LayerNorm (recomputed
+// per chunk, it is cheap), ONE 256-unit chunk of the MLP, partial fc2 output -> ws.  Pass 2 (grid.y = column slice):
+// x = x_mid + b2 + sum of the partials in fixed order (deterministic), then the follow-up projections, 8 column blocks per
+// workgroup.  Each workgroup streams a quarter of the weights, four times as many CUs pull them.
+template <int NMB, int MODE>
 __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   using K_ = Cfg<NMB>;
   constexpr int BM = K_::BM, HC = K_::HC, LDH = K_::LDH, LDA = K_::LDA;
@@ -225,7 +232,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
   const long long m0 = (long long)blockIdx.x * BM;
-  for (int i = t; i < p.H; i += NT) b1s[i] = p.b1[i];
+  if (MODE != 2)
+    for (int i = t; i < p.H; i += NT) b1s[i] = p.b1[i];
+  const long long MC = p.M * (long long)C;
 
   // token values of this wave's 32-channel slice: v[mb][e] = x[m0 + mb*32 + r][wave*32 + (e&3) + 8*(e>>2) + 4h]
   f32x16 v[NMB];
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     for (int e = 0; e < 16; ++e) v[mb][e] = 0.f;
 
   // ---- 1. attention output projection (accumulated into v, x is added afterwards)
-  if (p.att) {
+  if (MODE != 2 && p.att) {
     // att tile (fp32) -> bf16 [128][296], overlaid on the two (still unused) H buffers
     unsigned short* As = &Hs[0][0];
     const int q4 = p.Ko / 4;  // float4 per row
@@ -266,7 +275,21 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) xv = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
+      if (MODE == 2) {  // x after the projection (pass 1) + b2 + the MLP partials, in chunk order
+        if (m < p.M) {
+          const long long o = m * C + wave * 32 + 8 * g + 4 * h;
+          xv = *reinterpret_cast<const f32x4*>(p.ws + o);
+          for (int sidx = 0; sidx < p.H / Cfg<NMB>::HC; ++sidx) {
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(p.ws + (sidx + 1) * MC + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] += pv[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] += p.b2[wave * 32 + 8 * g + 4 * h + e];
+      } else if (m < p.M) {
+        xv = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += xv[e];
     }
@@ -289,12 +312,12 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
     }
   };
-  ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
+  if (MODE != 2) ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
   bf16x8 wq[PFQ];  // the weight-fragment queue, chained through the MLP and the follow-up projections
   // a projection runs in this workgroup when its row range meets the workgroup's rows (workgroup-uniform)
   auto active = [&](int q) { return q < p.n_next && m0 < p.next[q].row_hi && m0 + BM > p.next[q].row_lo; };
-  const bool tail_next = active(0) && wave < (p.next[0].N + 31) / 32;
-  {
+  const bool tail_next = MODE == 0 && active(0) && wave < (p.next[0].N + 31) / 32;
+  if (MODE != 2) {
     f32x16 acc2[NMB];
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
@@ -310,9 +333,10 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     // ONE fragment queue for the whole MLP: the wave consumes fc1(c0), fc2(c0), fc1(c1), ... strictly in this order, 16
     // k-steps each, so the queue always holds the next 16 fragments of that sequence (>= 16 MFMA k-steps of lookahead,
     // which is what an L2 round trip needs; two half-depth queues left every fragment ~250 cycles short)
-    fill_wq(wq, w1row);
+    const int c_lo = MODE == 1 ? (int)blockIdx.y : 0, c_hi = MODE == 1 ? c_lo + 1 : nchunk;
+    fill_wq(wq, w1row + (long long)c_lo * JW * (C / 16) * FS);
 #pragma unroll 1
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
       unsigned short* Hb = Hs[c & 1];
       // fc1: H^T block (hidden jb of this chunk) x token blocks NM1*mp ..
       f32x16 ha[NM1];
@@ -336,8 +360,28 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       __syncthreads();
       // fc2 partial: out^T block (channels of this wave) += W2[:, chunk] . H^T; refills the queue with the next chunk's fc1
       // fragments (after the last chunk: with the first follow-up projection's, or harmlessly with fc1(c0) again)
-      const unsigned short* after = c + 1 < nchunk ? w1row + (long long)(c + 1) * JW * (C / 16) * FS : tail;
+      const unsigned short* after = c + 1 < c_hi ? w1row + (long long)(c + 1) * JW * (C / 16) * FS : tail;
       gemm_wq<HC / 16, NMB>(acc2, wq, w2row + (long long)c * (HC / 16) * FS, after, &Hb[r * LDH + 8 * h], LDH, 0);
+    }
+    if (MODE == 1) {  // partial fc2 output of this chunk (+ x after the projection, once) -> workspace; pass 2 finishes
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        const long long m = m0 + mb * 32 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const long long o = m * C + wave * 32 + 8 * g + 4 * h;
+          f32x4 a4, x4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a4[e] = acc2[mb][4 * g + e];
+            x4[e] = v[mb][4 * g + e];
+          }
+          *reinterpret_cast<f32x4*>(p.ws + (blockIdx.y + 1) * MC + o) = a4;
+          if (blockIdx.y == 0) *reinterpret_cast<f32x4*>(p.ws + o) = x4;
+        }
+      }
+      return;
     }
     // x += MLP output
 #pragma unroll
@@ -347,7 +391,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += acc2[mb][4 * g + e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
   }
-  store_x();
+  if (MODE == 0 || blockIdx.y == 0) store_x();
 
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
   bool have = tail_next;  // the queue already holds this wave's first block of the projection
@@ -363,20 +407,21 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     ln_to_lds<NMB>(v, Xs, st, wave, lane, nx.eps, nx.lnw, nx.lnb);
     const int nblocks = (nx.N + 31) / 32;
     auto nrow_of = [&](int nb) { return nx.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
-    if (wave < nblocks && !have) fill_wq(wq, nrow_of(wave));
+    const int nb0 = MODE == 2 ? (int)blockIdx.y * 8 + wave : wave, nbstep = MODE == 2 ? 8 * (int)gridDim.y : 8;
+    if (nb0 < nblocks && !have) fill_wq(wq, nrow_of(nb0));
     // after this wave's last block the queue moves on to its first block of the next projection, if that one runs here
     const int qn = q + 1 < MVT_BLOCK_MAX_NEXT ? q + 1 : MVT_BLOCK_MAX_NEXT - 1;
     const unsigned short* chain = nullptr;
-    if (q + 1 < MVT_BLOCK_MAX_NEXT && active(q + 1) && wave < (p.next[qn].N + 31) / 32)
+    if (MODE == 0 && q + 1 < MVT_BLOCK_MAX_NEXT && active(q + 1) && wave < (p.next[qn].N + 31) / 32)
       chain = p.next[qn].w + ((long long)wave * (C / 16) * 64 + lane) * 8;
     have = chain != nullptr && wave < nblocks;
-    for (int nb = wave; nb < nblocks; nb += 8) {
+    for (int nb = nb0; nb < nblocks; nb += nbstep) {
       f32x16 acc[NMB];
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
-      gemm_wq<C / 16, NMB>(acc, wq, nrow_of(nb), nb + 8 < nblocks ? nrow_of(nb + 8) : (chain ? chain : nrow_of(nb)), &Xs[r * LDX + 8 * h], LDX, 0);
+      gemm_wq<C / 16, NMB>(acc, wq, nrow_of(nb), nb + nbstep < nblocks ? nrow_of(nb + nbstep) : (chain ? chain : nrow_of(nb)), &Xs[r * LDX + 8 * h], LDX, 0);
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
         const long long m = m0 + mb * 32 + r;
@@ -430,7 +475,7 @@ extern "C" int mvt_pack_frag_bf16(const unsigned short* w, int ld, int N, int K,
 extern "C" int mvt_block_fused_bf16(float* x, int ldx, const void* att, int att_bf16, int ldatt, int Ko, const unsigned short* wo, int ldwo,
                                     const float* bo, const unsigned short* w1, int ldw1, const float* b1, const unsigned short* w2,
                                     int ldw2, const float* b2, int H, const mvt_block_next* next, int n_next, long long M, int Cc,
-                                    void* stream) {
+                                    float* workspace, void* stream) {
   MVT_REQUIRE(x && w1 && b1 && w2 && b2 && M > 0 && Cc == C && H > 0 && H % 256 == 0 && H <= 4 * C);
   MVT_REQUIRE(ldx % 4 == 0 && ldx >= C);
   MVT_REQUIRE(!att || (wo && bo && Ko == 288 && ldatt % 4 == 0 && ldatt >= Ko));
@@ -451,9 +496,20 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const void* att, int att_
   }
   static const char* force = getenv("MVT_BLOCK_NMB");  // tuning override
   const int nmb = force ? atoi(force) : (M >= 4096 ? 2 : 1);  // 64-row workgroups measured 1.6x faster than 128-row ones at M = 12288
-  if (nmb == 2)
-    hipLaunchKernelGGL(block_fused_bf16<2>, dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
-  else
-    hipLaunchKernelGGL(block_fused_bf16<1>, dim3((unsigned)mvt_cdiv(M, 32)), dim3(NT), 0, mvt_stream(stream), a);
+  static const bool no_split = getenv("MVT_BLOCK_NOSPLIT") != nullptr;
+  a.ws = workspace;
+  if (nmb == 2) {
+    hipLaunchKernelGGL((block_fused_bf16<2, 0>), dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
+  } else if (workspace && !no_split && M <= 2048) {
+    MVT_REQUIRE((uintptr_t)workspace % 16 == 0);
+    const unsigned tiles = (unsigned)mvt_cdiv(M, 32);
+    hipLaunchKernelGGL((block_fused_bf16<1, 1>), dim3(tiles, (unsigned)(H / 256)), dim3(NT), 0, mvt_stream(stream), a);
+    int maxblk = 1;
+    for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
+    const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
+    hipLaunchKernelGGL((block_fused_bf16<1, 2>), dim3(tiles, slices), dim3(NT), 0, mvt_stream(stream), a);
+  } else {
+    hipLaunchKernelGGL((block_fused_bf16<1, 0>), dim3((unsigned)mvt_cdiv(M, 32)), dim3(NT), 0, mvt_stream(stream), a);
+  }
   return mvt_launch_status();
 }

@@ -36,7 +36,7 @@ SIGNATURES = {
     "mvt_instnorm_finish_slots": [P, I, P, I, LL, I, P],
     "mvt_ln_gemm_bf16": [P, I, P, P, F, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_pack_frag_bf16": [P, I, I, I, P, P],
-    "mvt_block_fused_bf16": [P, I, P, I, I, I, P, I, P, P, I, P, P, I, P, I, P, I, LL, I, P],
+    "mvt_block_fused_bf16": [P, I, P, I, I, I, P, I, P, P, I, P, P, I, P, I, P, I, LL, I, P, P],
     "mvt_mlp_fused_bf16": [P, I, P, I, P, P, I, P, LL, I, I, F, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
@@ -179,15 +179,17 @@ class BlockNext(C.Structure):
 BLOCK_MAX_NEXT = 3
 
 
-def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw2, b2, H, nexts, M, Cc):
+def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw2, b2, H, nexts, M, Cc, ws=None):
     """nexts: list of dicts(w, ldw, b, N, lnw, lnb, eps, y, ldy[, rows=(lo, hi)]) -- at most BLOCK_MAX_NEXT follow-up
-    projections; ``rows`` restricts one to a row range (y is always indexed by the global row)."""
+    projections; ``rows`` restricts one to a row range (y is always indexed by the global row).  ``ws``: optional fp32
+    workspace of (H/256 + 1) * M * Cc elements that lets M <= 2048 run cut over 4x more workgroups."""
+    assert ws is None or (ws.dtype == torch.float32 and ws.numel() >= (H // 256 + 1) * M * Cc)
     arr = (BlockNext * max(1, len(nexts)))()
     for i, nx in enumerate(nexts):
         arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],
                            nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)), 1 if nx["y"].dtype == torch.bfloat16 else 0)
     _call("mvt_block_fused_bf16", _ptr(x), ldx, _ptr(att), 1 if (att is not None and att.dtype == torch.bfloat16) else 0, ldatt, Ko, _ptr(wo), ldwo, _ptr(bo), _ptr(w1), ldw1, _ptr(b1), _ptr(w2),
-          ldw2, _ptr(b2), H, C.cast(arr, C.c_void_p), len(nexts), M, Cc, _stream())
+          ldw2, _ptr(b2), H, C.cast(arr, C.c_void_p), len(nexts), M, Cc, _ptr(ws), _stream())
 
 
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):

@@ -511,13 +511,13 @@ class MVTracker(nn.Module):
         self._lin(pk, u + "flow_head.4", h2, ldh, Mp, delta, ldd)
 
     # ---- fused path (precision "bf16", hidden 256): per layer 4 attention launches + 5 fused block launches
-    def _fused_block(self, pk, p, attn_key, x, rows, att, nexts):
+    def _fused_block(self, pk, p, attn_key, x, rows, att, nexts, ws=None):
         """x += att @ Wo^T + bo; x += MLP(LN(x)); then the follow-up projections of LN(x) listed in ``nexts``."""
         h = self.hidden
         no, n1, n2 = f"{p}.{attn_key}.to_out", p + ".mlp.fc1", p + ".mlp.fc2"
         inner = self.num_heads * self.dim_head
         hip.block_fused_bf16(x, h, att, inner, inner, pk[no + "#frag"], inner, pk[no][1], pk[n1 + "#frag"], h, pk[n1][1],
-                             pk[n2 + "#frag"], 4 * h, pk[n2][1], 4 * h, nexts, rows, h)
+                             pk[n2 + "#frag"], 4 * h, pk[n2][1], 4 * h, nexts, rows, h, ws=ws)
 
     def _next(self, pk, name, y, ldy, ln=None, eps=1e-6, rows=(0, 0)):
         _, b, n, k = pk[name]
@@ -545,6 +545,7 @@ class MVTracker(nn.Module):
         qkv_nx = torch.empty(M, 3 * inner, device=dev, dtype=tdt)
         qp = torch.empty(Mp, inner, device=dev, dtype=tdt)       # point <- virtual queries (computed right after the time block)
         att = torch.empty(M, inner, device=dev, dtype=tdt)
+        ws = torch.empty(5 * Mv * h, device=dev) if 4 * h == 1024 else None  # split path of the virtual-track blocks
         u = "updateformer."
         space_attn = hip.attention_bf16 if space_mfma else hip.attention
         time_attn = hip.attention_bf16 if space_mfma else hip.attention  # 12 keys pad to one 32-key MFMA block: still 1.4x the VALU kernel
@@ -568,14 +569,14 @@ class MVTracker(nn.Module):
             # virtual <- point
             space_attn(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, n, H,
                        dh)
-            self._fused_block(pk, v2p, "cross_attn", vt, Mv, att[Mp:], [self._next(pk, vs + ".attn.qkv", qkv[Mp:], 3 * inner)])
+            self._fused_block(pk, v2p, "cross_attn", vt, Mv, att[Mp:], [self._next(pk, vs + ".attn.qkv", qkv[Mp:], 3 * inner)], ws=ws)
             # virtual self attention
             space_attn(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, nv, H,
                        dh)
             nx = [self._next(pk, p2v + ".cross_attn.to_kv", qkv[Mp:, inner:], 3 * inner, pk[p2v + ".norm_context"], 1e-5)]
             if not last:  # the virtual rows are final for this layer: project the next layer's time q|k|v right here
                 nx.append(self._next(pk, nxt_qkv, qkv_nx[Mp:], 3 * inner))
-            self._fused_block(pk, vs, "attn", vt, Mv, att[Mp:], nx)
+            self._fused_block(pk, vs, "attn", vt, Mv, att[Mp:], nx, ws=ws)
             # point <- virtual
             space_attn(qp, inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[:Mp], inner, S, n, nv, H, dh)
             self._fused_block(pk, p2v, "cross_attn", pt, Mp, att[:Mp], [] if last else [self._next(pk, nxt_qkv, qkv_nx[:Mp], 3 * inner)])

@@ -86,7 +86,7 @@ def _unfrag(wf, N, K):
     return wf.reshape(-1)[:nb * 32 * K].reshape(nb, K // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(nb * 32, K)[:N].view(torch.bfloat16).float()
 
 
-def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw2, b2, H, nexts, M, Cc):
+def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw2, b2, H, nexts, M, Cc, ws=None):
     xv = _v(x, M, Cc, ldx)
     if att is not None:
         xv += _bf(_v(att, M, Ko, ldatt).float()) @ _unfrag(wo, Cc, Ko).t() + bo[:Cc]

@@ -316,6 +316,43 @@ def test_block_fused_bf16(hip, M, with_att, n_next):
         assert bool((ys[i][:, N:] == 3.0).all())
 
 
+@pytest.mark.parametrize("M,n_next", [(768, 2), (1000, 1), (50, 0), (768, 3)])
+def test_block_fused_split_path(hip, M, n_next):
+    """The two-launch path for small M (chunks of the MLP / column slices over separate workgroups) against the one-workgroup
+    kernel: x and every projection agree to fp32 summation order (the partial fc2 sums are added in a different order)."""
+    g = torch.Generator().manual_seed(M + n_next)
+    C, H, Ko = 256, 1024, 288
+    x = torch.randn(M, C, generator=g)
+    att = torch.randn(M, Ko, generator=g)
+
+    def hw(nn_, k):
+        w = torch.randn(nn_, k, generator=g) / math.sqrt(k)
+        hi = split(hip, G(pad_w(w)), False)[0]
+        fr = torch.empty((nn_ + 31) // 32 * 32 * k, device=DEV, dtype=torch.int16)
+        hip.pack_frag_bf16(hi, hi.shape[1], nn_, k, fr)
+        return fr
+
+    who, wh1, wh2 = hw(C, Ko), hw(H, C), hw(C, H)
+    bo, b1, b2 = (G(torch.randn(k_, generator=g) * 0.1) for k_ in (C, H, C))
+    Ns = [576, 864, 288][:n_next]
+    wn = [hw(N, C) for N in Ns]
+    bn = [G(torch.randn(N, generator=g) * 0.1) for N in Ns]
+    lnw, lnb = G(torch.randn(C, generator=g) * 0.3 + 1), G(torch.randn(C, generator=g) * 0.1)
+    res = []
+    for ws in (None, torch.full((5 * M * C,), float("nan"), device=DEV)):
+        xg = G(x)
+        ys = [torch.full((M, N), 5.0, device=DEV) for N in Ns]
+        nexts = [dict(w=wn[i], ldw=C, b=bn[i], N=N, y=ys[i], ldy=N, eps=1e-5 if i == 0 else 1e-6, **(dict(lnw=lnw, lnb=lnb) if i == 0 else {}),
+                      **(dict(rows=(32, M - 7)) if i == 2 else {})) for i, N in enumerate(Ns)]
+        hip.block_fused_bf16(xg, C, G(att), Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, H, b2, H, nexts, M, C, ws=ws)
+        torch.cuda.synchronize()
+        res.append((xg, ys))
+    assert rel_err(res[1][0], res[0][0].double().cpu()) < 1e-6
+    for a, b in zip(res[0][1], res[1][1]):
+        assert rel_err(b, a.double().cpu()) < 2e-3  # LayerNorm output is re-rounded to bf16: one-ulp flips of single operands
+        assert torch.equal(a == 5.0, b == 5.0)
+
+
 @pytest.mark.parametrize("M,cut", [(13056, 12288), (1000, 333), (200, 0)])
 def test_block_fused_row_ranges(hip, M, cut):
     """Three follow-up projections restricted to row ranges (one launch over point + virtual rows): rows outside a range

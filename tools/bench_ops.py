@@ -163,4 +163,9 @@ if "block" in which:
             nexts = [dict(w=mk(N, C), ldw=256, b=torch.randn(N, device=dev), N=N, y=torch.empty(M, N, device=dev), ldy=N, eps=1e-6) for N in Ns]
             t_f = timeit(lambda: hip.block_fused_bf16(x, C, att, Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, H, b2, H, nexts, M, C))
             t_n = timeit(lambda: hip.block_fused_bf16(x, C, None, Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, H, b2, H, [], M, C))
-            print(f"block_fused M={M} nexts={Ns}: {t_f:.1f} us   (MLP only: {t_n:.1f} us)")
+            extra = ""
+            if M <= 2048:
+                ws = torch.empty(5 * M * C, device=dev)
+                t_s = timeit(lambda: hip.block_fused_bf16(x, C, att, Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, H, b2, H, nexts, M, C, ws=ws))
+                extra = f"   split path: {t_s:.1f} us"
+            print(f"block_fused M={M} nexts={Ns}: {t_f:.1f} us   (MLP only: {t_n:.1f} us){extra}")
