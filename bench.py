@@ -87,7 +87,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("MVT_FORCE_SHARDED"):  # (the env switch rehearses the sharded code path on one GPU)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -182,7 +182,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or os.environ.get("MVT_FORCE_SHARDED"):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

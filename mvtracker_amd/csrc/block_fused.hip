@@ -352,7 +352,11 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         for (int g = 0; g < 4; ++g) {
           f32x4 o;
 #pragma unroll
+#ifdef MVT_ABL_NOGELU
+          for (int e = 0; e < 4; ++e) o[e] = ha[i][4 * g + e] + b1s[c * HC + jb * 32 + 8 * g + 4 * h + e];
+#else
           for (int e = 0; e < 4; ++e) o[e] = mvt_gelu_tanh(ha[i][4 * g + e] + b1s[c * HC + jb * 32 + 8 * g + 4 * h + e]);
+#endif
           const bf16x4 b = __builtin_convertvector(o, bf16x4);
           *reinterpret_cast<u32x2*>(&Hb[((NM1 * mp + i) * 32 + r) * LDH + jb * 32 + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, b);
         }

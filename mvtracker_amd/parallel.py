@@ -12,6 +12,7 @@ the refinement loop; the small outputs are all-gathered at the end when requeste
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -46,7 +47,7 @@ class ShardedTracker:
     def __call__(self, rgbs, depths, query_points, intrs, extrs, iters=4, gather_output=True):
         world, rank = self._world()
         m = self.model
-        if world == 1:
+        if world == 1 and not (os.environ.get("MVT_FORCE_SHARDED") and dist.is_available() and dist.is_initialized()):
             return m(rgbs, depths, query_points, intrs, extrs, iters=iters)
         _, V, T, _, H, W = rgbs.shape
         N = query_points.shape[1]

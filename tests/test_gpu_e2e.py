@@ -244,3 +244,22 @@ def test_forward_bf16_vs_autocast_oracle(model, W):
     ev = (model.last_vis_logits.cpu() - ro["vis_logits"]).abs().max().item()
     print(f"bf16: tracks rel err {et:.2e} (autocast-oracle tol {tol_t:.2e}), vis logits {ev:.2e} (tol {tol_v:.2e})")
     assert et < max(tol_t, 1e-4) and ev < max(tol_v, 1e-3)
+
+
+def test_sharded_path_on_one_gpu(model, monkeypatch):
+    """The multi-GPU code path (per-rank frame block -> RCCL all-gather of the level-0 features -> frame store handed to
+    the forward -> gathered outputs) rehearsed with a one-rank RCCL group: identical results to the direct call."""
+    import torch.distributed as dist
+    from mvtracker_amd.parallel import ShardedTracker
+    clip = synth.make_clip(21, V=2, T=18, H=128, W=128, N=48)
+    a = args_of(clip, DEV)
+    ref = model(*a, iters=2)
+    ref_t, ref_v = ref["traj_e"].clone(), ref["vis_e"].clone()
+    monkeypatch.setenv("MVT_FORCE_SHARDED", "1")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        out = ShardedTracker(model)(*a, iters=2)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(out["traj_e"], ref_t) and torch.equal(out["vis_e"], ref_v)
