@@ -58,16 +58,40 @@ class ShardedTracker:
         if t0 < T - m.S // 2:
             f32 = lambda t: t.to(torch.float32).contiguous()
             r0, d0, i0, e0 = f32(rgbs[0]), f32(depths[0]), f32(intrs[0]), f32(extrs[0])
-            cnt = (T - t0 + world - 1) // world  # frames per rank (last ranks may get fewer / none)
-            lo, hi = min(T, t0 + rank * cnt), min(T, t0 + (rank + 1) * cnt)
             hs, ws, C = H // m.stride, W // m.stride, m.latent_dim
-            local = torch.zeros(cnt, V, hs, ws, C, device=rgbs.device)
-            if hi > lo:
-                local[:hi - lo] = m.encode_frames(r0, t0=lo, t1=hi)[lo:hi]
-            gathered = self._all_gather(local, world)  # frames t0 .. t0 + world*cnt - 1
-            level0 = torch.zeros(T, V, hs, ws, C, device=rgbs.device)
-            level0[t0:] = gathered[:T - t0]
-            store = m.build_frame_store(r0, d0, i0, e0, t0=t0, level0=level0)
+            dev = rgbs.device
+            level0 = torch.empty(T, V, hs, ws, C, device=dev)
+            level0[:t0].zero_()  # (never read: no window starts before the first query frame)
+
+            def exchange_block(f0, f1):
+                cnt = (f1 - f0 + world - 1) // world
+                lo, hi = min(f1, f0 + rank * cnt), min(f1, f0 + (rank + 1) * cnt)
+                # (rows past a rank's share are frames >= f1 of the last ranks: gathered but never copied, so no memset)
+                local = torch.empty(cnt, V, hs, ws, C, device=dev)
+                if hi > lo:
+                    m.encode_frames(r0, t0=lo, t1=hi, out=local, out_t0=lo)
+                gathered = self._all_gather(local, world)  # frames f0 .. f0 + world*cnt - 1
+                level0[f0:f1] = gathered[:f1 - f0]
+
+            # The first window only reads frames [t0, t0+S): exchange those first and let the rest of the clip be encoded
+            # and all-gathered on a second stream while the first windows are refined (events order each window after
+            # the frames it reads, exactly like the single-GPU encoder overlap).
+            first_end = min(T, t0 + m.S)
+            overlap = m.overlap_encoder and first_end < T and dev.type == "cuda"
+            exchange_block(t0, first_end if overlap else T)
+            store = m.build_frame_store(r0, d0, i0, e0, t0=t0, level0=level0, t1=first_end if overlap else T)
+            if overlap:
+                main = torch.cuda.current_stream(dev)
+                side = m._side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    exchange_block(first_end, T)
+                    m.fill_frame_features(store, r0, first_end, T, level0=level0)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                store["pending"] = [(first_end, ev)]
+                for t_ in (r0, level0):  # allocated on the main stream, last used on the side stream
+                    t_.record_stream(side)
         res = m(rgbs, depths, query_points[:, a:b], intrs, extrs, iters=iters, frame_store=store)
         if not gather_output:
             return res

@@ -347,9 +347,9 @@ class MVTracker(nn.Module):
             self._inorm(y, n, hs * ws, 2 * C, st=st)
             self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C)
 
-    def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16, out=None):
+    def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16, out=None, out_t0=0):
         """rgbs (V,T,3,H,W) in [0,255] -> level-0 features (T,V,H/4,W/4,C); frames outside [t0,t1) are left zero
-        (or untouched when the result goes into ``out``)."""
+        (or untouched when the result goes into ``out``, whose first row is frame ``out_t0``)."""
         V, T, _, H, W = rgbs.shape
         t1 = T if t1 is None else t1
         pk = self._pack(rgbs.device)
@@ -360,7 +360,7 @@ class MVTracker(nn.Module):
             nt = min(step, t1 - a)
             x4 = torch.empty(nt * V, H, W, 4, device=rgbs.device)
             hip.rgb_to_nhwc4(rgbs, x4, V, T, H, W, a, nt)
-            self._encode(pk, x4, nt * V, H, W, F0[a:a + nt])
+            self._encode(pk, x4, nt * V, H, W, F0[a - out_t0:a - out_t0 + nt])
         return F0
 
     # ------------------------------------------------------------------ frame store (model_utils.py:420-482)
@@ -731,6 +731,7 @@ class MVTracker(nn.Module):
         if w < T - S // 2:
             if frame_store is not None:
                 store = frame_store
+                pending = list(frame_store.get("pending", ()))  # (first frame, event) of feature blocks still in flight
             elif not self.overlap_encoder or max(w, 0) + S >= T or dev.type != "cuda":
                 store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0))
             else:
