@@ -305,6 +305,8 @@ int mvt_attention(const float* q, int ldq, long long q_gs, long long q_is, const
 int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, const void* k, const void* v,
                        int ldkv, long long k_gs, long long k_is, void* o, int ldo, int groups, int nq, int nk,
                        int heads, int dh, int io_flags /* MVT_IO_IN_BF16: q, k, v are bf16 tensors; MVT_IO_OUT_BF16: o is */,
+                       float* workspace /* NULL, or 4 * groups*heads*ceil(nq/64) * 4352 floats: lets a long-key attention
+                                           with few (group, head) chunks cut its keys over 4 workgroups per chunk */,
                        void* stream);
 /* x[(n*S+s)*ld + 0:C] = v[n][0:C] for all s  (virtual-token broadcast, blocks.py:458-459). */
 int mvt_broadcast_rows(const float* v, float* x, int ld, int n, int S, int C, void* stream);

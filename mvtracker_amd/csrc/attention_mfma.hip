@@ -40,7 +40,9 @@ template <int KS>
 __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel(
     const float* __restrict__ q, int ldq, long long q_gs, long long q_is, const float* __restrict__ k, const float* __restrict__ v,
     int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads, int bf_in,
-    int bf_out) {
+    int bf_out, float* __restrict__ ws) {
+  // ws != null: the keys are additionally cut over gridDim.y workgroups; wave 0 leaves its (m, l, O) partial in ws and
+  // attention_merge_kernel finishes the softmax (the 64 virtual x 1024 point attention is only 72 (frame, head) chunks)
   constexpr int NW = KS == 1 ? 4 : KS;
   constexpr int VT = 64 * LDV;                              // bf16 elements of one wave's V^T image (64 d rows)
   constexpr int MERGE = KS > 1 ? (KS - 1) * 64 * 68 : 0;    // floats: per lane m[2], l[2], 64 accumulators
@@ -100,9 +102,12 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
   }
 
   const int nkb = (nk + 31) / 32;                       // key blocks
-  const int per = (nkb + KS - 1) / KS;
-  const int kb0 = KS == 1 ? 0 : wave * per;
-  const int kb1 = KS == 1 ? nkb : (kb0 + per < nkb ? kb0 + per : nkb);
+  const int gper = ws ? (nkb + (int)gridDim.y - 1) / (int)gridDim.y : nkb;   // ... of this workgroup
+  const int g0 = ws ? (int)blockIdx.y * gper : 0;
+  const int g1 = g0 + gper < nkb ? g0 + gper : nkb;
+  const int per = (gper + KS - 1) / KS;
+  const int kb0 = KS == 1 ? g0 : g0 + wave * per;
+  const int kb1 = KS == 1 ? g1 : (kb0 + per < g1 ? kb0 + per : g1);
   const long long kvbase = (g * k_gs) * ldkv + hd * DH;  // element offset (fp32 or bf16 tensors)
   const long long kstep = k_is * ldkv;
 
@@ -226,6 +231,85 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
     }
   }
   if (!chunk_ok) return;
+  if (ws) {
+    float* rr = ws + ((blockIdx.y * nchunk + chunk_id) * 64 + lane) * 68;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      rr[mb] = m[mb];
+      rr[2 + mb] = l[mb];
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rr[4 + (mb * 2 + db) * 16 + e] = oacc[mb][db][e];
+    }
+    return;
+  }
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float lt = l[mb] + __shfl_xor(l[mb], 32, 64);
+    const float inv = 1.0f / lt;
+    const int qi = qc * 64 + mb * 32 + r;
+    if (qi >= nq) continue;
+    const long long oo = (g * q_gs + (long long)qi * q_is) * ldo + hd * DH;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = db * 32 + 8 * gq + 4 * h;
+        if (d < DH) {
+          f32x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = oacc[mb][db][4 * gq + e] * inv;
+          store_act4(o, oo + d, t, bf_out);
+        }
+      }
+    }
+  }
+}
+
+// Combine the per-workgroup partials of a key-split attention (fixed order: deterministic) and write the output.
+__global__ __launch_bounds__(256) void attention_merge_kernel(const float* __restrict__ ws, int nsplit, long long nchunk, long long q_gs,
+                                                              long long q_is, float* __restrict__ o, int ldo, int nq, int heads,
+                                                              int bf_out) {
+  const int lane = threadIdx.x & 63;
+  const long long cid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cid >= nchunk) return;
+  const int r = lane & 31, h = lane >> 5;
+  const int chunks = (nq + 63) / 64;
+  const int qc = (int)(cid % chunks);
+  const int hd = (int)((cid / chunks) % heads);
+  const long long g = cid / ((long long)chunks * heads);
+  float m[2], l[2];
+  f32x16 oacc[2][2];
+  {
+    const float* rr = ws + (cid * 64 + lane) * 68;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      m[mb] = rr[mb];
+      l[mb] = rr[2 + mb];
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[mb][db][e] = rr[4 + (mb * 2 + db) * 16 + e];
+    }
+  }
+#pragma unroll 1
+  for (int w = 1; w < nsplit; ++w) {
+    const float* rr = ws + ((w * nchunk + cid) * 64 + lane) * 68;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const float mw = rr[mb];
+      const float mn = fmaxf(m[mb], mw);
+      const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
+      const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
+      l[mb] = l[mb] * ca + rr[2 + mb] * cb;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[mb][db][e] = oacc[mb][db][e] * ca + rr[4 + (mb * 2 + db) * 16 + e] * cb;
+      m[mb] = mn;
+    }
+  }
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     const float lt = l[mb] + __shfl_xor(l[mb], 32, 64);
@@ -253,7 +337,7 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
 
 extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, const void* k, const void* v,
                                   int ldkv, long long k_gs, long long k_is, void* o, int ldo, int groups, int nq, int nk,
-                                  int heads, int dh, int io_flags, void* stream) {
+                                  int heads, int dh, int io_flags, float* workspace, void* stream) {
   MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16)) == 0);
   const int bf_in = io_flags & MVT_IO_IN_BF16 ? 1 : 0, bf_out = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
   MVT_REQUIRE(!bf_in || (ldq % 8 == 0 && ldkv % 8 == 0));  // 16-B aligned rows
@@ -264,12 +348,27 @@ extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long l
   const long long nchunk = (long long)groups * heads * ((nq + 63) / 64);
 #define LAUNCH(KS, BLOCKS, THREADS)                                                                                        \
   hipLaunchKernelGGL((attention_mfma_kernel<KS>), dim3((unsigned)(BLOCKS)), dim3(THREADS), 0, mvt_stream(stream), (const float*)q, ldq, q_gs, \
-                     q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out)
+                     q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out, WS)
+  constexpr int NSPLIT = 4;
+  if (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0) {
+    // too few (group, head) chunks to fill the chip: cut the keys over NSPLIT workgroups per chunk as well
+    MVT_REQUIRE((uintptr_t)workspace % 16 == 0);
+#define WS workspace
+    hipLaunchKernelGGL((attention_mfma_kernel<4>), dim3((unsigned)nchunk, NSPLIT), dim3(256), 0, mvt_stream(stream), (const float*)q, ldq,
+                       q_gs, q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out,
+                       workspace);
+#undef WS
+    hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)mvt_cdiv(nchunk, 4)), dim3(256), 0, mvt_stream(stream), workspace, NSPLIT,
+                       nchunk, q_gs, q_is, (float*)o, ldo, nq, heads, bf_out);
+    return mvt_launch_status();
+  }
+#define WS nullptr
   if (nk >= 512 && nchunk < 1024) {
     LAUNCH(4, nchunk, 256);
   } else {
     LAUNCH(1, mvt_cdiv(nchunk, 4), 256);
   }
+#undef WS
 #undef LAUNCH
   return mvt_launch_status();
 }

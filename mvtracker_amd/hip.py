@@ -61,7 +61,7 @@ SIGNATURES = {
     "mvt_rowdot": [P, I, P, P, P, LL, I, P],
     "mvt_layernorm": [P, I, P, P, P, I, LL, I, F, P],
     "mvt_attention": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, P],
-    "mvt_attention_bf16": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, I, P],
+    "mvt_attention_bf16": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, I, P, P],
     "mvt_broadcast_rows": [P, P, I, I, I, I, P],
 }
 _RET = {"mvt_build_arch": C.c_char_p}
@@ -322,10 +322,16 @@ def attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk
           dh, _stream())
 
 
-def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
+def attention_ws_floats(groups, nq, heads):
+    """Workspace size (fp32 elements) of the key-split path of ``attention_bf16``."""
+    return 4 * groups * heads * ((nq + 63) // 64) * 64 * 68
+
+
+def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh, ws=None):
     assert q.dtype == k.dtype == v.dtype
+    assert ws is None or (ws.dtype == torch.float32 and ws.numel() >= attention_ws_floats(groups, nq, heads))
     _call("mvt_attention_bf16", _ptr(q), ldq, q_gs, q_is, _ptr(k), _ptr(v), ldkv, k_gs, k_is, _ptr(o), ldo, groups, nq, nk, heads,
-          dh, _io(q, o), _stream())
+          dh, _io(q, o), _ptr(ws), _stream())
 
 
 def broadcast_rows(v, x, ld, n, S, Cc):

@@ -546,6 +546,7 @@ class MVTracker(nn.Module):
         qp = torch.empty(Mp, inner, device=dev, dtype=tdt)       # point <- virtual queries (computed right after the time block)
         att = torch.empty(M, inner, device=dev, dtype=tdt)
         ws = torch.empty(5 * Mv * h, device=dev) if 4 * h == 1024 else None  # split path of the virtual-track blocks
+        aws = torch.empty(hip.attention_ws_floats(S, nv, H), device=dev) if space_mfma else None  # key-split virtual <- point attention
         u = "updateformer."
         space_attn = hip.attention_bf16 if space_mfma else hip.attention
         time_attn = hip.attention_bf16 if space_mfma else hip.attention  # 12 keys pad to one 32-key MFMA block: still 1.4x the VALU kernel
@@ -568,7 +569,7 @@ class MVTracker(nn.Module):
                                self._next(pk, v2p + ".cross_attn.to_q", qkv, 3 * inner, rows=(Mp, M))])
             # virtual <- point
             space_attn(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, n, H,
-                       dh)
+                       dh, **({"ws": aws} if space_mfma else {}))
             self._fused_block(pk, v2p, "cross_attn", vt, Mv, att[Mp:], [self._next(pk, vs + ".attn.qkv", qkv[Mp:], 3 * inner)], ws=ws)
             # virtual self attention
             space_attn(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, att[Mp:], inner, S, nv, nv, H,

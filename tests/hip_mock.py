@@ -370,7 +370,11 @@ def attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk
     torch.as_strided(o, (groups, nq, heads, dh), (q_gs * ldo, q_is * ldo, dh, 1)).copy_(y)
 
 
-def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh):
+def attention_ws_floats(groups, nq, heads):
+    return 4 * groups * heads * ((nq + 63) // 64) * 64 * 68
+
+
+def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh, ws=None):
     attention(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, nq, nk, heads, dh)
 
 
@@ -392,6 +396,6 @@ def install(monkeypatch):
     from mvtracker_amd import hip
     me = sys.modules[__name__]
     for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
-                 "depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
+                 "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

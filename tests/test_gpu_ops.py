@@ -870,6 +870,18 @@ def test_updater_bf16_token_tensors(hip):
         hip.attention_bf16(*args_of(qb, ob))
         torch.cuda.synchronize()
         assert torch.equal(of.to(torch.bfloat16), ob)
+    # key-split path (workspace given) of the virtual <- point attention: same result up to the merge order
+    o1, o2 = torch.zeros(M, inner, device=DEV), torch.zeros(M, inner, device=DEV)
+    n2 = 1024
+    qkv2 = G(torch.randn((n2 + nv) * S, 3 * inner, generator=g))
+    Mp2 = n2 * S
+    o1, o2 = torch.zeros((n2 + nv) * S, inner, device=DEV), torch.zeros((n2 + nv) * S, inner, device=DEV)
+    ws = torch.full((hip.attention_ws_floats(S, nv, H),), float("nan"), device=DEV)
+    hip.attention_bf16(qkv2[Mp2:], 3 * inner, 1, S, qkv2[:Mp2, inner:], qkv2[:Mp2, 2 * inner:], 3 * inner, 1, S, o1[Mp2:], inner, S, nv, n2, H, dh)
+    hip.attention_bf16(qkv2[Mp2:], 3 * inner, 1, S, qkv2[:Mp2, inner:], qkv2[:Mp2, 2 * inner:], 3 * inner, 1, S, o2[Mp2:], inner, S, nv, n2, H, dh,
+                       ws=ws)
+    torch.cuda.synchronize()
+    assert (o1 - o2).abs().max() < 2e-3 and float(o2[Mp2:].abs().max()) > 0  # P is rounded to bf16 relative to a different running max
     # time attention against fp64 softmax attention
     of = torch.zeros(M, inner, device=DEV)
     hip.attention_bf16(qf, 3 * inner, S, 1, qf[:, inner:], qf[:, 2 * inner:], 3 * inner, S, 1, of, inner, n + nv, S, S, H, dh)

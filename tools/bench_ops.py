@@ -82,6 +82,8 @@ if "attn" in which:
     print("attn time  %.1f us" % timeit(lambda: hip.attention(qkv, 3 * inner, S, 1, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, S, 1, out, inner, n + nv, S, S, Hh, dh)))
     print("attn v2p   %.1f us" % timeit(lambda: hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, n, Hh, dh)))
     print("attn vself %.1f us" % timeit(lambda: hip.attention(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, nv, Hh, dh)))
+    aws = torch.empty(hip.attention_ws_floats(S, nv, Hh), device=dev)
+    print("attn_bf16 v2p key-split %.1f us" % timeit(lambda: hip.attention_bf16(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, n, Hh, dh, ws=aws)))
     print("attn_bf16 time %.1f us" % timeit(lambda: hip.attention_bf16(qkv, 3 * inner, S, 1, qkv[:, inner:], qkv[:, 2 * inner:], 3 * inner, S, 1, out, inner, n + nv, S, S, Hh, dh)))
     for nm, f in (("v2p", lambda: hip.attention_bf16(qkv[Mp:], 3 * inner, 1, S, qkv[:Mp, inner:], qkv[:Mp, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, n, Hh, dh)),
                   ("vself", lambda: hip.attention_bf16(qkv[Mp:], 3 * inner, 1, S, qkv[Mp:, inner:], qkv[Mp:, 2 * inner:], 3 * inner, 1, S, out[Mp:], inner, S, nv, nv, Hh, dh)),
