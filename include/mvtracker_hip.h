@@ -221,7 +221,8 @@ int mvt_unproject(const float* depth_s, const float* kinv, const float* einv, fl
  * of which is monotonic, so it never exceeds the d2 of a point inside the box.  grid_w = grid_h = 0: tile t = points
  * [64t, 64t+64); grid_w, grid_h > 0 (multiples of 8, P = views*grid_h*grid_w in raster order): 8x8 pixel patches.
  * The segments are runs of tiles; only the merged result (mvt_knn_merge) is layout independent. */
-int mvt_tile_aabb(const float* xyz, long long P, int T, int grid_w, int grid_h, float* box /* [T][ceil(P/64)][8] */,
+int mvt_tile_aabb(const float* xyz, long long P, int T, int grid_w, int grid_h,
+                  float* box /* [T][ceil(P/64)][8] = lo.xyz, finite-point count, hi.xyz, 0 */,
                   void* stream);
 int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step,
                  int T, int K, int nseg, unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw,

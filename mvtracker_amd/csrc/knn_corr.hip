@@ -120,7 +120,7 @@ __device__ __forceinline__ long long tile_point(long long tile, int lane, int gr
   return (v * grid_h + ty * 8 + (lane >> 3)) * grid_w + tx * 8 + (lane & 7);
 }
 
-// box[frame][tile] = {lo.xyz, 0, hi.xyz, 0}; NaN points are ignored (fminf / fmaxf drop them), an all-NaN tile gets lo = +inf, hi = -inf
+// box[frame][tile] = {lo.xyz, number of finite points, hi.xyz, 0}; NaN points are ignored (fminf / fmaxf drop them), an all-NaN tile gets lo = +inf, hi = -inf
 __global__ __launch_bounds__(256) void tile_aabb_kernel(const float* __restrict__ xyz, long long P, long long ntiles, long long total,
                                                         int grid_w, int grid_h, float* __restrict__ box) {
   const int lane = threadIdx.x & 63;
@@ -130,13 +130,16 @@ __global__ __launch_bounds__(256) void tile_aabb_kernel(const float* __restrict_
   const long long c = tile_point(tile, lane, grid_w, grid_h);
   const float inf = __int_as_float(0x7f800000);
   float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+  bool finite = false;
   if (c < P) {
     const f32x4 p = *reinterpret_cast<const f32x4*>(xyz + (frame * P + c) * 4);
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
       if (p[e] == p[e]) lo[e] = hi[e] = p[e];
     }
+    finite = fabsf(p[0]) < inf && fabsf(p[1]) < inf && fabsf(p[2]) < inf;
   }
+  const int nfinite = __popcll(__ballot(finite));
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
 #pragma unroll
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void tile_aabb_kernel(const float* __restrict_
   }
   if (lane == 0) {
     float* b = box + id * 8;
-    *reinterpret_cast<f32x4*>(b) = (f32x4){lo[0], lo[1], lo[2], 0.f};
+    *reinterpret_cast<f32x4*>(b) = (f32x4){lo[0], lo[1], lo[2], (float)nfinite};  // .w: points with finite coordinates
     *reinterpret_cast<f32x4*>(b + 4) = (f32x4){hi[0], hi[1], hi[2], 0.f};
   }
 }
@@ -207,6 +210,37 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
         if (!(d2s == d2s)) d2s = __int_as_float(0x7f800000);  // NaN coordinates: no bound
       }
       thr[i] = uniform_f(wave_max(d2s));
+    }
+  }
+  if (fbox && !seed_idx) {
+    // Unseeded scan: a tile with >= K finite points puts the K-th nearest neighbour within the FARTHEST corner of its box
+    // (per-axis max gap, same monotonic arithmetic as the scan, so the bound is >= the d2 of every point of the tile).
+    // The minimum over this wave's tiles is an exact initial threshold; without it the first 64 tiles are scanned in full.
+    float ub[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) ub[i] = __int_as_float(0x7f800000);
+    for (long long tb = t0; tb < t1; tb += 64) {
+      const long long mt = tb + lane;
+      if (mt < t1) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(fbox + mt * 8), hi = *reinterpret_cast<const f32x4*>(fbox + mt * 8 + 4);
+        if (lo[3] >= (float)K) {
+#pragma unroll
+          for (int i = 0; i < Q; ++i) {
+            const float dx = fmaxf(fabsf(lo[0] - qx[i]), fabsf(hi[0] - qx[i]));
+            const float dy = fmaxf(fabsf(lo[1] - qy[i]), fabsf(hi[1] - qy[i]));
+            const float dz = fmaxf(fabsf(lo[2] - qz[i]), fabsf(hi[2] - qz[i]));
+            const float u = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+            ub[i] = u < ub[i] ? u : ub[i];  // (a NaN bound -- NaN query -- never replaces +inf)
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      float u = ub[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) u = fminf(u, __shfl_xor(u, o, 64));
+      thr[i] = uniform_f(u);
     }
   }
   const unsigned long long lt_mask = (1ULL << lane) - 1ULL;

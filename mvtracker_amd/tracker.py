@@ -109,6 +109,7 @@ class MVTracker(nn.Module):
         self.mfma_attention = True
         self.overlap_encoder = os.environ.get("MVT_OVERLAP", "1") != "0"  # encode later frames on a second stream
         self._side = {}
+        self._scratch = {}
         self.bf16_tokens = os.environ.get("MVT_BF16_TOK", "1") != "0"  # bf16 mode: q/k/v and attention outputs stored as bf16
         self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
@@ -504,11 +505,20 @@ class MVTracker(nn.Module):
             self._mlp_residual(pk, p, pt, Mp, xn[:Mp], hbuf[:Mp])
         od = self.out_dim
         ldh = _round_up(od, 4)
-        h1 = torch.zeros(Mp, ldh, device=dev)
-        h2 = torch.zeros(Mp, ldh, device=dev)
+        h1, h2 = self._flow_scratch(Mp, ldh, dev)
         self._lin(pk, u + "flow_head.0", pt, h, Mp, h1, ldh, hip.ACT_RELU)
         self._lin(pk, u + "flow_head.2", h1, ldh, Mp, h2, ldh, hip.ACT_RELU)
         self._lin(pk, u + "flow_head.4", h2, ldh, Mp, delta, ldd)
+
+    def _flow_scratch(self, rows, ld, dev):
+        """Hidden activations of the flow head, (rows, ld) with ld = round_up(out_dim, 4): the GEMMs write out_dim columns, the
+        pad columns are read as K padding by the next layer and must be zero -- zeroed once, then reused by every call."""
+        key = (rows, ld, dev.type, dev.index)
+        if key not in self._scratch:
+            if len(self._scratch) > 8:
+                self._scratch.clear()
+            self._scratch[key] = (torch.zeros(rows, ld, device=dev), torch.zeros(rows, ld, device=dev))
+        return self._scratch[key]
 
     # ---- fused path (precision "bf16", hidden 256): per layer 4 attention launches + 5 fused block launches
     def _fused_block(self, pk, p, attn_key, x, rows, att, nexts, ws=None):
@@ -584,8 +594,7 @@ class MVTracker(nn.Module):
             qkv, qkv_nx = qkv_nx, qkv
         od = self.out_dim
         ldh = _round_up(od, 4)
-        h1 = torch.zeros(Mp, ldh, device=dev)
-        h2 = torch.zeros(Mp, ldh, device=dev)
+        h1, h2 = self._flow_scratch(Mp, ldh, dev)
         self._lin(pk, u + "flow_head.0", pt, h, Mp, h1, ldh, hip.ACT_RELU)
         self._lin(pk, u + "flow_head.2", h1, ldh, Mp, h2, ldh, hip.ACT_RELU)
         self._lin(pk, u + "flow_head.4", h2, ldh, Mp, delta, ldd)
@@ -661,7 +670,8 @@ class MVTracker(nn.Module):
                 trace.setdefault("delta", []).append(delta[:, :self.out_dim].reshape(n, S, -1).clone())
             hip.delta_split(delta, ldd, *pk["ffeats_norm"], coords, dn, n * S, C, nan_flag)
             self._lin(pk, "ffeats_updater.0", dn, C, n * S, ffeats, C, hip.ACT_GELU_ERF, R=ffeats, ldr=C)
-            preds.append(coords.clone())
+            if trace is not None or it + 1 == iters:  # (the intermediate estimates only feed the training loss upstream)
+                preds.append(coords.clone())
         vis = torch.empty(n, S, device=dev)
         hip.rowdot(ffeats, C, *pk["vis"], vis, n * S, C)
         if trace is not None:
