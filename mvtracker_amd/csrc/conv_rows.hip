@@ -43,8 +43,8 @@ constexpr int MAXC = 512;        // input channels the in-kernel normalisation s
 // Geometry of one workgroup: TM row blocks per wave, four waves stacked in y, kernel size KS (1 or 3), stride S (1 or 2).
 // The patch is stored row by row in 80-B pixel slots.  For the stride-2 3x3 kernel a patch row holds its even columns
 // first and its odd columns after them, so that the pixels 2r + kw of tap kw are consecutive slots again.
-template <int TM, int KS, int S> struct Geo {
-  static constexpr int ROWS = 4 * TM;                                  // output rows
+template <int TM, int KS, int S, int NW> struct Geo {
+  static constexpr int ROWS = NW * TM;                                 // output rows (NW waves stacked in y)
   static constexpr int PR = KS == 1 ? ROWS : S * (ROWS - 1) + 3;       // patch rows
   static constexpr int PC = KS == 1 ? TC : S * (TC - 1) + 3;           // patch columns
   static constexpr int HALF = (PC + 1) / 2;                            // even columns of a split row
@@ -57,14 +57,15 @@ template <int TM, int KS, int S> struct Geo {
   __host__ __device__ static constexpr int row_step() { return KS == 1 ? 1 : S; }  // patch rows per output row
 };
 
-template <int TM, int TN, int KS, int S, bool INB>
-__global__ __launch_bounds__(256) void conv_rows_bf16(RowsArgs p) {
-  using G = Geo<TM, KS, S>;
+template <int TM, int TN, int KS, int S, bool INB, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_rows_bf16(RowsArgs p) {
+  using G = Geo<TM, KS, S, NW>;
+  constexpr int NT = 64 * NW;
   constexpr int BN = TN * 32;
   constexpr int ppp = INB ? 4 : 8;   // 16-B pieces per pixel
   constexpr int cpp = INB ? 8 : 4;   // channels per piece
-  constexpr int NPL = (G::NSLOT * ppp + 255) / 256;    // pieces per thread per chunk
-  constexpr int NWF = (KS * BN * 4 + 255) / 256;        // 16-B weight pieces per thread per stage (KS taps x BN rows x 64 B)
+  constexpr int NPL = (G::NSLOT * ppp + NT - 1) / NT;    // pieces per thread per chunk
+  constexpr int NWF = (KS * BN * 4 + NT - 1) / NT;        // 16-B weight pieces per thread per stage (KS taps x BN rows x 64 B)
   __shared__ __attribute__((aligned(16))) unsigned short Ps[G::NSLOT * LDP];
   __shared__ __attribute__((aligned(16))) unsigned short Ws[KS * BN * LDP];
   __shared__ __attribute__((aligned(16))) float Sst[2 * MAXC];  // (mean, rstd) of the input channels of this image
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_rows_bf16(RowsArgs p) {
   bool pk[NPL];             // inside the image
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
-    const int f = t + 256 * i;
+    const int f = t + NT * i;
     const int sl = f / ppp, q = f - sl * ppp;
     const int py = sl / G::RS, cs = sl - py * G::RS;
     const int px = G::SPLITROW ? (cs < G::HALF ? 2 * cs : 2 * (cs - G::HALF) + 1) : cs;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_rows_bf16(RowsArgs p) {
   bool wk[NWF];
 #pragma unroll
   for (int i = 0; i < NWF; ++i) {
-    const int u = t + 256 * i;
+    const int u = t + NT * i;
     const int row = u >> 2, part = u & 3;
     const int tap = row / BN, n = row - tap * BN;
     wk[i] = row < KS * BN && n0 + n < p.Cout;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_rows_bf16(RowsArgs p) {
   };
   // InstanceNorm statistics: staged in LDS once (they would otherwise occupy 16 registers through the MFMA loop)
   if (p.in_stats) {
-    for (int i = t; i < 2 * p.Cin; i += 256) Sst[i] = p.in_stats[img * 2 * p.Cin + i];
+    for (int i = t; i < 2 * p.Cin; i += NT) Sst[i] = p.in_stats[img * 2 * p.Cin + i];
     __syncthreads();
   }
   auto norm4 = [&](f32x4 v, const f32x4& m, const f32x4& rs) {
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_rows_bf16(RowsArgs p) {
     if (INB) {
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
-        const int f = t + 256 * i, sl = f / ppp;
+        const int f = t + NT * i, sl = f / ppp;
         if (sl >= G::NSLOT) continue;
         u32x4 w = __builtin_bit_cast(u32x4, rp[i]);
         if (p.in_stats) {
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_rows_bf16(RowsArgs p) {
     } else {
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
-        const int f = t + 256 * i, sl = f / ppp;
+        const int f = t + NT * i, sl = f / ppp;
         if (sl >= G::NSLOT) continue;
         f32x4 v = rp[i];
         if (p.in_stats) v = norm4(v, sm0, sr0);
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_rows_bf16(RowsArgs p) {
   auto store_w = [&]() {
 #pragma unroll
     for (int i = 0; i < NWF; ++i) {
-      const int u = t + 256 * i, row = u >> 2;
+      const int u = t + NT * i, row = u >> 2;
       if (row >= KS * BN) continue;
       *reinterpret_cast<u32x4*>(&Ws[row * LDP + (u & 3) * 8]) = wk[i] ? rw[i] : (u32x4){0u, 0u, 0u, 0u};
     }
@@ -433,23 +434,26 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
   const bool n96 = Cout % 64 != 0 && Cout % 96 == 0;
   const int bn = n96 ? 96 : 64;
   // (64-channel tiles keep three workgroups per CU with bf16 tensors: measured 1.4x faster than 128-channel tiles at one per CU)
-#define LAUNCH(TM_, KS_, S_)                                                                                                        \
+#define LAUNCH(TM_, KS_, S_, NW_)                                                                                                   \
   do {                                                                                                                             \
-    const long long tiles = (long long)n * mvt_cdiv(Ho, 4 * TM_) * mvt_cdiv(Wo, TC) * mvt_cdiv(Cout, bn);                          \
+    const long long tiles = (long long)n * mvt_cdiv(Ho, NW_ * TM_) * mvt_cdiv(Wo, TC) * mvt_cdiv(Cout, bn);                        \
     MVT_REQUIRE(tiles < (1LL << 31));                                                                                              \
     const dim3 grid((unsigned)tiles);                                                                                              \
     if (n96) {                                                                                                                     \
-      if (a.in_bf16) hipLaunchKernelGGL((conv_rows_bf16<TM_, 3, KS_, S_, true>), grid, dim3(256), 0, stream, a);                   \
-      else hipLaunchKernelGGL((conv_rows_bf16<TM_, 3, KS_, S_, false>), grid, dim3(256), 0, stream, a);                            \
+      if (a.in_bf16) hipLaunchKernelGGL((conv_rows_bf16<TM_, 3, KS_, S_, true, NW_>), grid, dim3(64 * NW_), 0, stream, a);         \
+      else hipLaunchKernelGGL((conv_rows_bf16<TM_, 3, KS_, S_, false, NW_>), grid, dim3(64 * NW_), 0, stream, a);                  \
     } else {                                                                                                                       \
-      if (a.in_bf16) hipLaunchKernelGGL((conv_rows_bf16<TM_, 2, KS_, S_, true>), grid, dim3(256), 0, stream, a);                   \
-      else hipLaunchKernelGGL((conv_rows_bf16<TM_, 2, KS_, S_, false>), grid, dim3(256), 0, stream, a);                            \
+      if (a.in_bf16) hipLaunchKernelGGL((conv_rows_bf16<TM_, 2, KS_, S_, true, NW_>), grid, dim3(64 * NW_), 0, stream, a);         \
+      else hipLaunchKernelGGL((conv_rows_bf16<TM_, 2, KS_, S_, false, NW_>), grid, dim3(64 * NW_), 0, stream, a);                  \
     }                                                                                                                              \
   } while (0)
-  if (ksize == 3 && stride == 1) LAUNCH(2, 3, 1);
-  else if (ksize == 3) LAUNCH(1, 3, 2);   // the stride-2 patch is four times larger per output pixel: 4 x 32 pixel tiles
-  else if (stride == 1) LAUNCH(2, 1, 1);
-  else LAUNCH(2, 1, 2);
+  static const int nw8 = getenv("MVT_ROWS_NW8") ? atoi(getenv("MVT_ROWS_NW8")) : 0;  // tuning override
+  if (ksize == 3 && stride == 1 && nw8 == 1 && Ho % 16 == 0) LAUNCH(2, 3, 1, 8);
+  else if (ksize == 3 && stride == 1 && nw8 == 2) LAUNCH(1, 3, 1, 4);
+  else if (ksize == 3 && stride == 1) LAUNCH(2, 3, 1, 4);
+  else if (ksize == 3) LAUNCH(1, 3, 2, 4);   // the stride-2 patch is four times larger per output pixel: 4 x 32 pixel tiles
+  else if (stride == 1) LAUNCH(2, 1, 1, 4);
+  else LAUNCH(2, 1, 2, 4);
 #undef LAUNCH
   return mvt_launch_status();
 }
