@@ -263,3 +263,33 @@ def test_sharded_path_on_one_gpu(model, monkeypatch):
     finally:
         dist.destroy_process_group()
     assert torch.equal(out["traj_e"], ref_t) and torch.equal(out["vis_e"], ref_v)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_nonsquare_odd_pyramid(model, W, prec):
+    """96x160 images: 24x40 features, pyramid levels 12x20 / 6x10 / 3x5 (not multiples of 8 -> linear kNN tiles, partial conv
+    tiles, a level with fewer points than a wave).  fp32 against the oracle (one window, first iteration teacher-forced
+    neighbour sets must agree); bf16 must stay within the bf16 budget of the fp32 result."""
+    clip = synth.make_clip(5, V=2, T=12, H=96, W=160, N=19)
+    a = args_of(clip, DEV)
+    old = model.precision
+    try:
+        model.precision = "fp32"
+        tr = []
+        r32 = model(*a, iters=2, trace=tr)
+        t32 = r32["traj_e"].clone()
+        if prec == "fp32":
+            otr = {}
+            ro = O.tracker_forward(W, CFG, *args_of(clip), iters=2, knn_mode="exact", trace=otr)
+            for l in range(4):
+                assert torch.equal(tr[0]["knn_idx"][0][l].cpu().long(), otr["windows"][0]["knn_idx"][l].permute(1, 0, 2))
+            rel = ((t32.cpu() - ro["traj_e"]).abs().max() / ro["traj_e"].abs().max()).item()
+            assert rel < 1e-4, rel
+        else:
+            model.precision = "bf16"
+            rb = model(*a, iters=2)
+            model.check_finite()
+            rel = ((rb["traj_e"] - t32).abs().max() / t32.abs().max()).item()
+            assert rel < 2e-2, rel
+    finally:
+        model.precision = old
