@@ -160,6 +160,14 @@ class EvaluationPredictor(torch.nn.Module):
             vis_e = torch.zeros(1, T, num_points, device=dev)
             qt = query_points_3d[0, :, 0].long().cpu().tolist()
             qh = torch.cat([query_points_3d[0, :, 1:], torch.ones(num_points, 1, device=dev)], 1)
+            # The N forwards differ only in their queries: encoder, feature pyramid and point clouds are built ONCE and
+            # shared (the reference re-encodes the clip for every query).  Every forward reads
+            # frames >= its own first query frame only, so one store from the earliest query frame serves them all.
+            if hasattr(self.model, "build_frame_store"):
+                f32 = lambda t_: t_.to(torch.float32).contiguous()
+                t_first = 0 if (self.grid_size > 0 or not qt) else max(0, min(qt))  # (the global support grid starts at frame 0)
+                fwd["frame_store"] = self.model.build_frame_store(f32(rgbs[0]), f32(depths[0]), f32(intrs[0]), f32(extrs[0]),
+                                                                  t0=t_first)
             for i in range(num_points):
                 t = qt[i]
                 rows = []
