@@ -158,6 +158,9 @@ int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 whe
 /* rgbs [V][T][3][H][W] (values 0..255) -> x [T_sel][V][H][W][4] = (2*(rgb/255)-1, 0) for frames
  * t0..t0+nt-1 (mvtracker.py:565-567 normalisation + channels-last repack). */
 int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream);
+/* same from uint8 frames, the storage type of the sample files (demo.py:650, 922-929): the clip stays 1 byte per value in HBM
+ * and over PCIe; (float)u8 is exact, so the result is bit-identical to converting first. */
+int mvt_rgb_u8_to_nhwc4(const unsigned char* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream);
 
 /* nearest-neighbour resize of [n][C][Hi][Wi] planes to [n][C][Ho][Wo] with torch's index rule
  * (evaluation_predictor_3dpt.py:76-81, F.interpolate(mode="nearest")). */

@@ -5,7 +5,8 @@
 
 namespace {
 
-__global__ void rgb_to_nhwc4_kernel(const float* __restrict__ rgbs, float* __restrict__ out, int V, int T, int H, int W,
+template <typename TIN>
+__global__ void rgb_to_nhwc4_kernel(const TIN* __restrict__ rgbs, float* __restrict__ out, int V, int T, int H, int W,
                                     int t0, int nt) {
   const long long hw = (long long)H * W;
   const long long total = (long long)nt * V * hw;
@@ -13,11 +14,11 @@ __global__ void rgb_to_nhwc4_kernel(const float* __restrict__ rgbs, float* __res
     long long img = i / hw;
     long long pix = i - img * hw;
     int tt = (int)(img / V), v = (int)(img - (long long)tt * V);
-    const float* src = rgbs + (((long long)v * T + (t0 + tt)) * 3) * hw + pix;
+    const TIN* src = rgbs + (((long long)v * T + (t0 + tt)) * 3) * hw + pix;
     f32x4 o;
-    o[0] = 2.0f * (src[0] / 255.0f) - 1.0f;
-    o[1] = 2.0f * (src[hw] / 255.0f) - 1.0f;
-    o[2] = 2.0f * (src[2 * hw] / 255.0f) - 1.0f;
+    o[0] = 2.0f * ((float)src[0] / 255.0f) - 1.0f;
+    o[1] = 2.0f * ((float)src[hw] / 255.0f) - 1.0f;
+    o[2] = 2.0f * ((float)src[2 * hw] / 255.0f) - 1.0f;
     o[3] = 0.0f;
     *reinterpret_cast<f32x4*>(out + i * 4) = o;
   }
@@ -204,7 +205,15 @@ inline unsigned grid_for(long long total, int block = 256) {
 extern "C" int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream) {
   MVT_REQUIRE(rgbs && out && V > 0 && T > 0 && H > 0 && W > 0 && t0 >= 0 && nt > 0 && t0 + nt <= T);
   long long total = (long long)nt * V * H * W;
-  hipLaunchKernelGGL(rgb_to_nhwc4_kernel, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), rgbs, out, V, T, H, W, t0, nt);
+  hipLaunchKernelGGL(rgb_to_nhwc4_kernel<float>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), rgbs, out, V, T, H, W, t0, nt);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_rgb_u8_to_nhwc4(const unsigned char* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream) {
+  MVT_REQUIRE(rgbs && out && V > 0 && T > 0 && H > 0 && W > 0 && t0 >= 0 && nt > 0 && t0 + nt <= T);
+  long long total = (long long)nt * V * H * W;
+  hipLaunchKernelGGL(rgb_to_nhwc4_kernel<unsigned char>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), rgbs, out, V, T, H, W,
+                     t0, nt);
   return mvt_launch_status();
 }
 

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mvt_block_fused_bf16": [P, I, P, I, I, I, P, I, P, P, I, P, P, I, P, I, P, I, LL, I, P, P],
     "mvt_mlp_fused_bf16": [P, I, P, I, P, P, I, P, LL, I, I, F, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
+    "mvt_rgb_u8_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
     "mvt_instnorm_stats": [P, I, P, P, I, LL, I, I, P],
     "mvt_instnorm_apply": [P, P, P, P, P, I, LL, I, I, P],
@@ -197,7 +198,11 @@ def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
 
 
 def rgb_to_nhwc4(rgbs, out, V, T, H, W, t0, nt):
-    _call("mvt_rgb_to_nhwc4", _ptr(_f32c(rgbs)), _ptr(out), V, T, H, W, t0, nt, _stream())
+    if rgbs.dtype == torch.uint8:
+        assert rgbs.is_contiguous()
+        _call("mvt_rgb_u8_to_nhwc4", _ptr(rgbs), _ptr(out), V, T, H, W, t0, nt, _stream())
+    else:
+        _call("mvt_rgb_to_nhwc4", _ptr(_f32c(rgbs)), _ptr(out), V, T, H, W, t0, nt, _stream())
 
 
 def resize_nearest(x, out, planes, Hi, Wi, Ho, Wo):

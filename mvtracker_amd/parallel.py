@@ -57,7 +57,8 @@ class ShardedTracker:
         store = None
         if t0 < T - m.S // 2:
             f32 = lambda t: t.to(torch.float32).contiguous()
-            r0, d0, i0, e0 = f32(rgbs[0]), f32(depths[0]), f32(intrs[0]), f32(extrs[0])
+            r0 = rgbs[0].contiguous() if rgbs.dtype == torch.uint8 else f32(rgbs[0])
+            d0, i0, e0 = f32(depths[0]), f32(intrs[0]), f32(extrs[0])
             hs, ws, C = H // m.stride, W // m.stride, m.latent_dim
             dev = rgbs.device
             level0 = torch.empty(T, V, hs, ws, C, device=dev)

@@ -124,7 +124,10 @@ class EvaluationPredictor(torch.nn.Module):
         hip.require_device(rgbs)
         dev = rgbs.device
         V, T = num_views, num_frames
-        rgbs = rgbs.to(torch.float32).contiguous()
+        # (uint8 frames stay uint8 unless they have to be resized: the encoder's first kernel converts them)
+        if not (rgbs.dtype == torch.uint8 and self.interp_shape is None):
+            rgbs = rgbs.to(torch.float32)
+        rgbs = rgbs.contiguous()
         depths = depths.to(torch.float32).contiguous()
         intrs = intrs.to(torch.float32)
         extrs = extrs.to(torch.float32)
@@ -166,7 +169,8 @@ class EvaluationPredictor(torch.nn.Module):
             if hasattr(self.model, "build_frame_store"):
                 f32 = lambda t_: t_.to(torch.float32).contiguous()
                 t_first = 0 if (self.grid_size > 0 or not qt) else max(0, min(qt))  # (the global support grid starts at frame 0)
-                fwd["frame_store"] = self.model.build_frame_store(f32(rgbs[0]), f32(depths[0]), f32(intrs[0]), f32(extrs[0]),
+                r0 = rgbs[0].contiguous() if rgbs.dtype == torch.uint8 else f32(rgbs[0])
+                fwd["frame_store"] = self.model.build_frame_store(r0, f32(depths[0]), f32(intrs[0]), f32(extrs[0]),
                                                                   t0=t_first)
             for i in range(num_points):
                 t = qt[i]

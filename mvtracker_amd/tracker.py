@@ -714,7 +714,9 @@ class MVTracker(nn.Module):
         dev = rgbs.device
         V, T, S, C, N = num_views, num_frames, self.S, self.latent_dim, num_points
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
-        rgbs, depths, intrs, extrs, query_points = map(f32, (rgbs[0], depths[0], intrs[0], extrs[0], query_points[0]))
+        # (uint8 frames -- the sample files' storage type -- stay uint8: the encoder's first kernel converts them)
+        rgbs = rgbs[0].to(dev).contiguous() if rgbs.dtype == torch.uint8 else f32(rgbs[0])
+        depths, intrs, extrs, query_points = map(f32, (depths[0], intrs[0], extrs[0], query_points[0]))
 
         # the one host sync of the call: integer query frames (mvtracker.py:489, truncation toward zero)
         qt_dev = query_points[:, 0].long()

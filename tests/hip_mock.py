@@ -161,7 +161,7 @@ def conv2d(x, wt, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0
 
 
 def rgb_to_nhwc4(rgbs, out, V, T, H, W, t0, nt):
-    x = 2 * (rgbs[:, t0:t0 + nt] / 255.0) - 1.0  # (V,nt,3,H,W)
+    x = 2 * (rgbs[:, t0:t0 + nt].float() / 255.0) - 1.0  # (V,nt,3,H,W)
     o = torch.as_strided(out, (nt, V, H, W, 4), (V * H * W * 4, H * W * 4, W * 4, 4, 1))
     o[..., :3] = x.permute(1, 0, 3, 4, 2)
     o[..., 3] = 0

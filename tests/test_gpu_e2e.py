@@ -293,3 +293,15 @@ def test_forward_nonsquare_odd_pyramid(model, W, prec):
             assert rel < 2e-2, rel
     finally:
         model.precision = old
+
+
+def test_uint8_frames_bit_identical(model):
+    """uint8 clips (the sample files' storage type) go to the encoder without a float32 copy; results are bit-identical."""
+    clip = synth.make_clip(33, V=2, T=12, H=96, W=128, N=12)
+    a = args_of(clip, DEV)
+    a[0] = a[0].round().clamp(0, 255)
+    r1 = model(*a, iters=2)["traj_e"].clone()
+    b = list(a)
+    b[0] = a[0].to(torch.uint8)
+    r2 = model(*b, iters=2)["traj_e"]
+    assert torch.equal(r1, r2)

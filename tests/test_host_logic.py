@@ -96,3 +96,29 @@ def test_forward_sequence(model, golden, name):
     np.testing.assert_allclose(r["vis_e"].numpy(), g["vis_exact"], atol=5e-3)
     np.testing.assert_allclose(r["feat_init"].numpy(), g["feat_init_exact"], rtol=1e-3, atol=1e-4)
     model.check_finite()
+
+
+def test_sample_io_roundtrip(tmp_path):
+    """Sample NPZ (demo.py:650, 922-929) -> tensors with a batch dimension, uint8 frames kept uint8; result NPZ keys of
+    demo.py:1093-1118."""
+    import numpy as np
+    from mvtracker_amd import sample_io
+    rng = np.random.default_rng(0)
+    V, Tn, H, W, N = 2, 5, 16, 24, 7
+    src = dict(rgbs=rng.integers(0, 256, (V, Tn, 3, H, W), dtype=np.uint8), depths=rng.random((V, Tn, 1, H, W), dtype=np.float32) + 1,
+               intrs=np.tile(np.array([[20., 0, 12], [0, 20, 8], [0, 0, 1]], np.float32), (V, Tn, 1, 1)),
+               extrs=np.tile(np.eye(4, dtype=np.float32)[:3], (V, Tn, 1, 1)), query_points=rng.random((N, 4), dtype=np.float32),
+               camera_ids=np.array(["a", "b"]))
+    p = tmp_path / "sample.npz"
+    np.savez(p, **src)
+    s = sample_io.load_sample(str(p), device="cpu")
+    assert s["rgbs"].dtype == torch.uint8 and tuple(s["rgbs"].shape) == (1, V, Tn, 3, H, W)
+    assert tuple(s["query_points_3d"].shape) == (1, N, 4) and list(s["camera_ids"]) == ["a", "b"]
+    s2 = sample_io.load_sample(str(p), device="cpu", temporal_stride=2, spatial_downsample=2)
+    assert tuple(s2["rgbs"].shape) == (1, V, 3, 3, H // 2, W // 2)
+    assert np.allclose(s2["intrs"][0, 0, 0].numpy(), [[10, 0, 6], [0, 10, 4], [0, 0, 1]])
+    out = tmp_path / "res.npz"
+    sample_io.save_result(str(out), torch.zeros(1, Tn, N, 3), torch.ones(1, Tn, N, dtype=torch.bool), s)
+    z = np.load(out, allow_pickle=False)
+    assert z["tracks_3d"].shape == (Tn, N, 3) and z["visibilities"].shape == (Tn, N) and z["query_points"].shape == (N, 4)
+    assert z["rgbs"].dtype == np.uint8 and str(z["tracker"]) == "mvtracker"
