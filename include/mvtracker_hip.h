@@ -195,6 +195,13 @@ int mvt_invert_cameras(const float* intrs, const float* extrs, float* kinv, floa
 /* depths [V][T][H][W] -> level-0 strided depth [T][V][H/s][W/s], nearest: source pixel (s*i, s*j)
  * (mvtracker.py:558-562). */
 int mvt_depth_subsample(const float* depths, float* out, int V, int T, int H, int W, int s, void* stream);
+/* View assignment of MonocularToMultiViewAdapter (monocular_baselines.py:630-680): for every query
+ * (t, x, y, z) the view whose depth map, sampled bilinearly at the query's projection at frame t, exceeds the query's camera
+ * depth the most (-1e4 for projections outside the image or behind the camera); the first maximum wins.
+ * depths [V][T][H][W], intrs [V][T][3][3], extrs [V][T][3][4], query_points [N][4]; view_out [N] int32;
+ * xyz_out NULL or [V][N][3] = (pixel x, pixel y, camera z) of every query in every view. */
+int mvt_adapter_best_view(const float* depths, const float* intrs, const float* extrs, const float* query_points, int V, int T,
+                          int H, int W, int N, int* view_out, float* xyz_out, void* stream);
 /* 2x2 average pool of channels-last [n][h][w][C] -> [n][h/2][w/2][C] (model_utils.py:440). */
 int mvt_avgpool2(const float* in, float* out, long long n, int h, int w, int C, void* stream);
 /* xyz_l [T][V][h_l][w_l][4] from level-0 strided depth [T][V][hs][ws] (nearest-subsampled by

@@ -103,6 +103,54 @@ inline unsigned grid_for(long long total) {
   return (unsigned)(g > 256 * 32 ? 256 * 32 : (g < 1 ? 1 : g));
 }
 
+// View assignment of the monocular-to-multi-view adapter (monocular_baselines.py:630-680): project a query into every view
+// at its query frame, sample that view's depth map (bilinear_sample2d, model_utils.py:81-165: four clamped taps, weights
+// from the unclamped corners), score = sampled depth - camera z (-1e4 - z outside the image or behind the camera) and take
+// the first maximum over the views.  One thread per query.
+__global__ void adapter_best_view_kernel(const float* __restrict__ depths, const float* __restrict__ intrs, const float* __restrict__ extrs,
+                                         const float* __restrict__ qp, int V, int T, int H, int W, int N, int* __restrict__ view_out,
+                                         float* __restrict__ xyz_out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int t = (int)qp[n * 4];  // .long(): truncation toward zero
+  t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+  const float px = qp[n * 4 + 1], py = qp[n * 4 + 2], pz = qp[n * 4 + 3];
+  float best = -INFINITY;
+  int bv = 0;
+  for (int v = 0; v < V; ++v) {
+    const float* E = extrs + ((long long)v * T + t) * 12;
+    const float* K = intrs + ((long long)v * T + t) * 9;
+    float cam[3], ph[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cam[i] = ((E[i * 4] * px + E[i * 4 + 1] * py) + E[i * 4 + 2] * pz) + E[i * 4 + 3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ph[i] = (K[i * 3] * cam[0] + K[i * 3 + 1] * cam[1]) + K[i * 3 + 2] * cam[2];
+    const float x = ph[0] / ph[2], y = ph[1] / ph[2], z = cam[2];
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+    const float* im = depths + ((long long)v * T + t) * H * W;
+    const float x1f = (float)(x0 + 1), y1f = (float)(y0 + 1);
+    const float w00 = (x1f - x) * (y1f - y), w01 = (x - xf) * (y1f - y), w10 = (x1f - x) * (y - yf), w11 = (x - xf) * (y - yf);
+    float d = ((w00 * im[cy0 * W + cx0] + w01 * im[cy0 * W + cx1]) + w10 * im[cy1 * W + cx0]) + w11 * im[cy1 * W + cx1];
+    const bool outside = x < 0.f || x >= (float)W || y < 0.f || y >= (float)H || z < 0.f;
+    if (outside) d = -1e4f;
+    const float score = d - z;
+    if (xyz_out) {
+      float* o = xyz_out + ((long long)v * N + n) * 3;
+      o[0] = x;
+      o[1] = y;
+      o[2] = z;
+    }
+    if (score > best) {  // strict: the first maximum wins (torch.argmax)
+      best = score;
+      bv = v;
+    }
+  }
+  view_out[n] = bv;
+}
+
 }  // namespace
 
 extern "C" int mvt_invert_cameras(const float* intrs, const float* extrs, float* kinv, float* einv, int n, void* stream) {
@@ -132,5 +180,13 @@ extern "C" int mvt_unproject(const float* depth_s, const float* kinv, const floa
   long long total = (long long)T * V * (hs >> level) * (ws >> level);
   hipLaunchKernelGGL(unproject_kernel, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), depth_s, kinv, einv, xyz, V, T, hs, ws,
                      stride, level);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_adapter_best_view(const float* depths, const float* intrs, const float* extrs, const float* query_points, int V, int T,
+                                     int H, int W, int N, int* view_out, float* xyz_out, void* stream) {
+  MVT_REQUIRE(depths && intrs && extrs && query_points && view_out && V > 0 && T > 0 && H > 0 && W > 0 && N > 0);
+  hipLaunchKernelGGL(adapter_best_view_kernel, dim3((unsigned)mvt_cdiv(N, 128)), dim3(128), 0, mvt_stream(stream), depths, intrs, extrs,
+                     query_points, V, T, H, W, N, view_out, xyz_out);
   return mvt_launch_status();
 }

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mvt_tile_aabb": [P, LL, I, I, I, P, P],
     "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P, I, I, P],
     "mvt_knn_merge": [P, I, I, I, I, LL, P, P],
+    "mvt_adapter_best_view": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mvt_knn_scan_levels": [I, P, P, I, I, I, I, I, I, I, P],
     "mvt_knn_merge_levels": [I, P, I, I, I, P],
     "mvt_corr_gather_dot": [I, P, P, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
@@ -277,6 +278,11 @@ def knn_scan_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k=0):
 def knn_merge_levels(levels, N, S, K):
     arr = _knn_levels(levels)
     _call("mvt_knn_merge_levels", len(levels), C.cast(arr, C.c_void_p), N, S, K, _stream())
+
+
+def adapter_best_view(depths, intrs, extrs, query_points, V, T, H, W, N, view_out, xyz_out=None):
+    _call("mvt_adapter_best_view", _ptr(_f32c(depths)), _ptr(_f32c(intrs)), _ptr(_f32c(extrs)), _ptr(_f32c(query_points)), V, T, H, W, N,
+          _ptr(view_out), _ptr(xyz_out), _stream())
 
 
 def knn_merge(keys, N, S, K, nseg, Pn, idx_out):

@@ -726,3 +726,29 @@ def predictor_forward(W, cfg, rgbs, depths, query_points_3d, intrs, extrs, inter
     vis = res["vis_e"][:, :, :n]
     return {"traj_e": res["traj_e"][:, :, :n], "vis_e": vis > visibility_threshold, "vis_e_as_prob": vis,
             "vis_logits": res["vis_logits"][:, :, :n], "support_points": support, "intrs": intrs}
+
+
+def adapter_best_view(depths: Tensor, query_points: Tensor, intrs: Tensor, extrs: Tensor) -> Tensor:
+    """View assignment of MonocularToMultiViewAdapter.forward (monocular_baselines.py:630-680).
+
+    depths (V,T,1,H,W), query_points (N,4), intrs (V,T,3,3), extrs (V,T,3,4) -> (N,) int64."""
+    V, T, _, H, W = depths.shape
+    N = query_points.shape[0]
+    qt = query_points[:, 0].long()
+    xyz = query_points[:, 1:]
+    xy = torch.zeros(V, N, 2)
+    zc = torch.zeros(V, N, 1)
+    dv = torch.zeros(V, N, 1)
+    for t in qt.unique():
+        m = qt == t
+        wh = torch.cat([xyz[m], torch.ones_like(xyz[m][:, :1])], -1)
+        cam = torch.einsum("Aij,Bj->ABi", extrs[:, t], wh)
+        ph = torch.einsum("Aij,ABj->ABi", intrs[:, t], cam)
+        xy[:, m] = ph[..., :2] / ph[..., 2:]
+        zc[:, m] = cam[..., -1:]
+        for v in range(V):
+            dv[v, m] = bilinear_sample2d(depths[v, t][None], xy[v, m, 0][None], xy[v, m, 1][None])[0].permute(1, 0)
+    outside = (xy[..., 0] < 0) | (xy[..., 0] >= W) | (xy[..., 1] < 0) | (xy[..., 1] >= H) | (zc[..., 0] < 0)
+    dv = dv.clone()
+    dv[outside] = -1e4
+    return (dv - zc).argmax(0).squeeze(-1)

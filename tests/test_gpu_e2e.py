@@ -305,3 +305,18 @@ def test_uint8_frames_bit_identical(model):
     b[0] = a[0].to(torch.uint8)
     r2 = model(*b, iters=2)["traj_e"]
     assert torch.equal(r1, r2)
+
+
+def test_adapter_view_assignment_golden(golden):
+    """Integer view indices of the monocular-to-multi-view adapter: bit-exact against the reference fixture and the oracle."""
+    from mvtracker_amd.adapter import assign_views
+    g = golden("adapter_view_assignment")
+    clip = synth.make_clip(int(g["seed"]), V=int(g["V"]), T=int(g["T"]), H=int(g["H"]), W=int(g["W"]), N=int(g["N"]), late_queries=True,
+                           query_frames=(2, 5))
+    q = T(g["query_points"])
+    bv, xy, z = assign_views(T(clip["depths"]).to(DEV), q.to(DEV), T(clip["intrs"]).to(DEV), T(clip["extrs"]).to(DEV), return_projections=True)
+    assert np.array_equal(bv[0].cpu().numpy(), g["best_view"])
+    pix, zc = O.project_to_view(q[0, :, 1:][None].expand(4, -1, -1), T(clip["intrs"][0, :, 0]), T(clip["extrs"][0, :, 0]))
+    m = q[0, :, 0].long() == 0  # queries of frame 0 (static cameras in the synthetic clip, any frame would do)
+    # (queries pushed next to a camera plane project to huge pixel coordinates: relative check)
+    assert ((xy[0].cpu()[:, m] - pix[:, m]).abs() / (1 + pix[:, m].abs())).max() < 1e-4 and (z[0].cpu()[:, m] - zc[:, m]).abs().max() < 1e-5

@@ -158,3 +158,13 @@ def test_helpers(golden):
     close(O.bilinear_sample2d(T(g["im"]), T(g["xs"]), T(g["ys"])), g["bil"])
     close(O.grid_points(5, (48, 64)), g["grid5"])
     close(O.grid_points(3, (50, 50), center=(20.5, 31.25)), g["grid3c"])
+
+
+def test_adapter_view_assignment(golden):
+    """MonocularToMultiViewAdapter's integer best-view index (monocular_baselines.py:630-680), reference-generated fixture
+    (tests/golden/make_golden_adapter.py): bit-exact."""
+    g = golden("adapter_view_assignment")
+    clip = synth.make_clip(int(g["seed"]), V=int(g["V"]), T=int(g["T"]), H=int(g["H"]), W=int(g["W"]), N=int(g["N"]), late_queries=True,
+                           query_frames=(2, 5))
+    bv = O.adapter_best_view(T(clip["depths"][0]), T(g["query_points"][0]), T(clip["intrs"][0]), T(clip["extrs"][0]))
+    assert np.array_equal(bv.numpy(), g["best_view"])
