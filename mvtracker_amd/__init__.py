@@ -5,7 +5,7 @@
 ``synth`` (numpy only) can be imported without the HIP library; everything else loads
 libmvtracker_hip.so on import and raises if it is missing -- there is no CPU fallback.
 """
-__all__ = ["MVTracker", "EvaluationPredictor", "load_mvtracker", "hip", "synth"]
+__all__ = ["MVTracker", "EvaluationPredictor", "load_mvtracker", "hip", "synth", "sample_io", "adapter", "geometry", "parallel"]
 
 
 def __getattr__(name):
@@ -18,7 +18,7 @@ def __getattr__(name):
     if name == "load_mvtracker":
         from .factory import load_mvtracker
         return load_mvtracker
-    if name in ("hip", "synth"):
+    if name in ("hip", "synth", "sample_io", "adapter", "geometry", "parallel"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

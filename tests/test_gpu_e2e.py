@@ -320,3 +320,12 @@ def test_adapter_view_assignment_golden(golden):
     m = q[0, :, 0].long() == 0  # queries of frame 0 (static cameras in the synthetic clip, any frame would do)
     # (queries pushed next to a camera plane project to huge pixel coordinates: relative check)
     assert ((xy[0].cpu()[:, m] - pix[:, m]).abs() / (1 + pix[:, m].abs())).max() < 1e-4 and (z[0].cpu()[:, m] - zc[:, m]).abs().max() < 1e-5
+
+
+def test_world_to_pixel_golden(golden):
+    from mvtracker_amd.geometry import project_tracks, world_to_pixel
+    g = golden("helpers")
+    pix, z = world_to_pixel(T(g["world"]).to(DEV), T(g["intrs"]).to(DEV), T(g["extrs"]).to(DEV))
+    assert (pix.cpu() - T(g["pix"])).abs().max() < 1e-3 and (z.cpu() - T(g["z"])).abs().max() < 1e-5
+    t2 = project_tracks(T(g["world"]).to(DEV)[None], T(g["intrs"]).to(DEV)[None, None], T(g["extrs"]).to(DEV)[None, None])
+    assert tuple(t2.shape) == (1, 1, 4, 9, 2) and torch.equal(t2[0, 0], pix)
