@@ -40,6 +40,124 @@ constexpr int CK = 32;           // channels per chunk
 constexpr int LDP = CK + 8;      // bf16 per pixel / weight-row slot (80 B)
 constexpr int MAXC = 512;        // input channels the in-kernel normalisation supports
 
+// Shared epilogue of the row-tile kernels: bias, output (fp32 / bf16), per-32-pixel statistics.  acc[i][j] is the 32 x 32
+// block (row i of this wave, 32-channel block j); yw = first output row of the wave.
+template <int TM, int TN, bool QUADS>
+__device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const RowsArgs& p, long long img, int Ho, int Wo, int yw, int x0,
+                                              int n0, int tiles_x, int tx, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const bool interior = x0 + TC <= Wo;
+  const int esz = p.out_bf16 ? 2 : 4;
+  const bool pairs = ((p.Cout | p.ldo) & 1) == 0;  // lane pairs (n, n+1) are both valid or both invalid, rows stay 4-B aligned
+  const int odd = lane & 1;
+  // (the quad transpose costs a few registers: it is compiled in only where it does not lower the occupancy)
+  const bool quads = QUADS && ((p.Cout | p.ldo) & 3) == 0 && ((uintptr_t)p.out & 15) == 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + j * 32 + r;
+    const bool nok = n < p.Cout;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+    const int lane_off = (4 * h * p.ldo + n) * esz;  // bytes
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int y = yw + i;  // wave-uniform
+      if (y >= Ho) continue;
+      char* rowp = reinterpret_cast<char*>(p.out) + (((img * Ho + y) * (long long)Wo + x0) * p.ldo) * esz;  // wave-uniform
+      float s1 = 0.f, s2 = 0.f;
+      if (quads) {
+        // 4 x 4 transpose inside every lane quad: registers 4g .. 4g+3 are four neighbouring pixels of channel n; after two
+        // DPP exchanges lane k of the quad owns channels (n & ~3) .. +3 of pixel 4h + 8g + k: one 8-B (bf16) / 16-B (fp32) store
+        const int k4 = lane & 3, k2 = (lane >> 1) & 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[i][j][4 * g + e] + bv;
+            if (nok && (interior || x0 + 4 * h + 8 * g + e < Wo)) {
+              s1 += v[e];
+              s2 = fmaf(v[e], v[e], s2);
+            }
+          }
+          float lo[2], hi[2];  // per pixel pair pp (pixels 2pp + odd): channels (n & ~1), (n & ~1) + 1
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const float send = odd ? v[2 * pp] : v[2 * pp + 1];
+            const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));  // [1,0,3,2]
+            lo[pp] = odd ? recv : v[2 * pp];
+            hi[pp] = odd ? v[2 * pp + 1] : recv;
+          }
+          // lanes 0,1 of the quad keep pair 0 (pixels 0,1) and send pair 1; lanes 2,3 keep pair 1 (pixels 2,3) and send pair 0
+          const float slo = k2 ? lo[0] : lo[1], shi = k2 ? hi[0] : hi[1];
+          const float rlo = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(slo), 0x4E, 0xF, 0xF, true));  // [2,3,0,1]
+          const float rhi = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(shi), 0x4E, 0xF, 0xF, true));
+          const float klo = k2 ? lo[1] : lo[0], khi = k2 ? hi[1] : hi[0];
+          // channels in order: the pair that came from the lanes with bit 1 clear first
+          const float c0 = k2 ? rlo : klo, c1 = k2 ? rhi : khi, c2 = k2 ? klo : rlo, c3 = k2 ? khi : rhi;
+          const int dx = 8 * g + k4;
+          if (nok && (interior || x0 + 4 * h + dx < Wo)) {
+            char* q = rowp + dx * p.ldo * esz + lane_off - k4 * esz;
+            if (p.out_bf16) {
+              uint2 w;
+              w.x = (unsigned)mvt_bf16_bits(c0) | ((unsigned)mvt_bf16_bits(c1) << 16);
+              w.y = (unsigned)mvt_bf16_bits(c2) | ((unsigned)mvt_bf16_bits(c3) << 16);
+              *reinterpret_cast<uint2*>(q) = w;
+            } else {
+              *reinterpret_cast<f32x4*>(q) = (f32x4){c0, c1, c2, c3};
+            }
+          }
+        }
+      } else if (pairs) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const int dx = (e & 3) + 8 * (e >> 2);
+          const float v0 = acc[i][j][e] + bv, v1 = acc[i][j][e + 1] + bv;
+          const bool ok0 = nok && (interior || x0 + 4 * h + dx < Wo), ok1 = nok && (interior || x0 + 4 * h + dx + 1 < Wo);
+          if (ok0) {
+            s1 += v0;
+            s2 = fmaf(v0, v0, s2);
+          }
+          if (ok1) {
+            s1 += v1;
+            s2 = fmaf(v1, v1, s2);
+          }
+          // even lane sends v1 (pixel e+1) and keeps v0; odd lane sends v0 and keeps v1
+          const float send = odd ? v0 : v1;
+          const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+          const float lo = odd ? recv : v0, hi = odd ? v1 : recv;  // channels (n & ~1, (n & ~1) + 1) of pixel dx + odd
+          if (odd ? ok1 : ok0) {
+            char* q = rowp + (dx + odd) * p.ldo * esz + lane_off - odd * esz;
+            if (p.out_bf16) *reinterpret_cast<unsigned*>(q) = (unsigned)mvt_bf16_bits(lo) | ((unsigned)mvt_bf16_bits(hi) << 16);
+            else *reinterpret_cast<float2*>(q) = make_float2(lo, hi);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dx = (e & 3) + 8 * (e >> 2);
+          if (nok && (interior || x0 + 4 * h + dx < Wo)) {
+            const float v = acc[i][j][e] + bv;
+            char* q = rowp + dx * p.ldo * esz + lane_off;
+            if (p.out_bf16) *reinterpret_cast<unsigned short*>(q) = mvt_bf16_bits(v);
+            else *reinterpret_cast<float*>(q) = v;
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+          }
+        }
+      }
+      if (p.out_part) {  // one writer per (row segment, channel): deterministic
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0 && nok) {
+          float* pp = p.out_part + ((img * p.slots + (long long)y * tiles_x + tx) * p.Cout + n) * 2;
+          pp[0] = s1;
+          pp[1] = s2;
+        }
+      }
+    }
+  }
+}
+
 // Geometry of one workgroup: TM row blocks per wave, four waves stacked in y, kernel size KS (1 or 3), stride S (1 or 2).
 // The patch is stored row by row in 80-B pixel slots.  For the stride-2 3x3 kernel a patch row holds its even columns
 // first and its odd columns after them, so that the pixels 2r + kw of tap kw are consecutive slots again.
@@ -240,46 +358,12 @@ __global__ __launch_bounds__(64 * NW) void conv_rows_bf16(RowsArgs p) {
     }
   }
 
-  // ---- epilogue: D[pixel][cout]: cout on the lanes (coalesced 128-B rows), pixels (e&3) + 8(e>>2) + 4h in the registers.
-  // A row's address is a wave-uniform base (SGPRs) plus one 32-bit lane offset; the sixteen pixels of a register block
-  // differ by compile-time multiples of ldo.
-  const bool interior = x0 + TC <= Wo;
-  const int esz = p.out_bf16 ? 2 : 4;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + j * 32 + r;
-    const bool nok = n < p.Cout;
-    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
-    const int lane_off = (4 * h * p.ldo + n) * esz;  // bytes
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int y = y0 + wm * TM + i;  // wave-uniform
-      if (y >= Ho) continue;
-      char* rowp = reinterpret_cast<char*>(p.out) + (((img * Ho + y) * (long long)Wo + x0) * p.ldo) * esz;  // wave-uniform
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int dx = (e & 3) + 8 * (e >> 2);
-        if (nok && (interior || x0 + 4 * h + dx < Wo)) {
-          const float v = acc[i][j][e] + bv;
-          char* q = rowp + dx * p.ldo * esz + lane_off;
-          if (p.out_bf16) *reinterpret_cast<unsigned short*>(q) = mvt_bf16_bits(v);
-          else *reinterpret_cast<float*>(q) = v;
-          s1 += v;
-          s2 = fmaf(v, v, s2);
-        }
-      }
-      if (p.out_part) {  // one writer per (row segment, channel): deterministic
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (h == 0 && nok) {
-          float* pp = p.out_part + ((img * p.slots + (long long)y * tiles_x + tx) * p.Cout + n) * 2;
-          pp[0] = s1;
-          pp[1] = s2;
-        }
-      }
-    }
-  }
+  // ---- epilogue: D[pixel][cout]: cout on the lanes, pixels (e&3) + 8(e>>2) + 4h in the registers.  A row's address is a
+  // wave-uniform base (SGPRs) plus one 32-bit lane offset.  Neighbouring lanes hold neighbouring channels of the same
+  // pixel: lane pairs swap one value (DPP) so that the even lane owns channels (n, n+1) of pixel e and the odd lane the
+  // same channels of pixel e+1 -- one 4-byte (bf16) / 8-byte (fp32) store per lane and register PAIR instead of a 2-byte
+  // store per register (the scalar bf16 stores alone were a third of the 64-channel layers' time).
+  epilogue_rows<TM, TN, TN == 3>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, n0, tiles_x, tx, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,43 +455,7 @@ __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
     }
   }
 
-  const bool interior = x0 + TC <= Wo;
-  const int esz = p.out_bf16 ? 2 : 4;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = j * 32 + r;
-    const bool nok = n < p.Cout;
-    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
-    const int lane_off = (4 * h * p.ldo + n) * esz;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int y = y0 + wm * TM + i;
-      if (y >= Ho) continue;
-      char* rowp = reinterpret_cast<char*>(p.out) + (((img * Ho + y) * (long long)Wo + x0) * p.ldo) * esz;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int dx = (e & 3) + 8 * (e >> 2);
-        if (nok && (interior || x0 + 4 * h + dx < Wo)) {
-          const float v = acc[i][j][e] + bv;
-          char* q = rowp + dx * p.ldo * esz + lane_off;
-          if (p.out_bf16) *reinterpret_cast<unsigned short*>(q) = mvt_bf16_bits(v);
-          else *reinterpret_cast<float*>(q) = v;
-          s1 += v;
-          s2 = fmaf(v, v, s2);
-        }
-      }
-      if (p.out_part) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (h == 0 && nok) {
-          float* pp = p.out_part + ((img * p.slots + (long long)y * tiles_x + tx) * p.Cout + n) * 2;
-          pp[0] = s1;
-          pp[1] = s2;
-        }
-      }
-    }
-  }
+  epilogue_rows<TM, TN, true>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, 0, tiles_x, tx, lane);
 }
 
 }  // namespace
