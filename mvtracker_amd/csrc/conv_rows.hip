@@ -42,10 +42,65 @@ constexpr int MAXC = 512;        // input channels the in-kernel normalisation s
 
 // Shared epilogue of the row-tile kernels: bias, output (fp32 / bf16), per-32-pixel statistics.  acc[i][j] is the 32 x 32
 // block (row i of this wave, 32-channel block j); yw = first output row of the wave.
-template <int TM, int TN, bool QUADS>
+// Elements of the per-wave LDS staging tile of the bf16 epilogue: 32 pixels x (BN + 8) channels
+template <int TN> constexpr int stage_elems() { return 32 * (TN * 32 + 8); }
+
+template <int TM, int TN, bool QUADS, bool STAGED>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const RowsArgs& p, long long img, int Ho, int Wo, int yw, int x0,
-                                              int n0, int tiles_x, int tx, int lane) {
+                                              int n0, int tiles_x, int tx, int lane, unsigned short* stage) {
   const int r = lane & 31, h = lane >> 5;
+  if (STAGED) {  // (compile-time: with both paths in one kernel the accumulators are copied out ahead of the branch -> +50 VGPRs)
+    // bf16 output through LDS: the accumulator layout (channel on the lane, 16 pixels in the registers) would store 2-4 bytes
+    // per lane; staged as [pixel][channel], every lane stores 16 contiguous bytes and a pixel's channels leave as whole
+    // 128-B lines (the scattered stores were still a quarter of the 64-channel layers' time).  `stage` is wave-private.
+    constexpr int BN = TN * 32, LDT = BN + 8, PPX = BN / 8;  // row stride (bf16), 16-B pieces per pixel
+    const bool interior = x0 + TC <= Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int y = yw + i;  // wave-uniform
+      if (y >= Ho) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + r;
+        const bool nok = n < p.Cout;
+        const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dx = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float v = acc[i][j][e] + bv;
+          stage[dx * LDT + j * 32 + r] = mvt_bf16_bits(v);
+          if (nok && (interior || x0 + dx < Wo)) {
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+          }
+          if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four accumulator registers at a time (VGPR budget)
+        }
+        if (p.out_part) {  // one writer per (row segment, channel): deterministic
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (h == 0 && nok) {
+            float* pp = p.out_part + ((img * p.slots + (long long)y * tiles_x + tx) * p.Cout + n) * 2;
+            pp[0] = s1;
+            pp[1] = s2;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one 32 x 32 block at a time: a single VGPR decides the occupancy of these kernels
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written as 16-bit elements and read as 128-bit vectors
+      unsigned short* rowp = reinterpret_cast<unsigned short*>(p.out) + ((img * Ho + y) * (long long)Wo + x0) * p.ldo + n0;
+#pragma unroll
+      for (int k = 0; k < (32 * PPX + 63) / 64; ++k) {
+        const int pc = lane + 64 * k;
+        const int px = pc / PPX, c8 = pc - px * PPX;
+        if (pc < 32 * PPX && x0 + px < Wo && n0 + c8 * 8 < p.Cout)
+          *reinterpret_cast<u32x4*>(rowp + (long long)px * p.ldo + c8 * 8) = *reinterpret_cast<const u32x4*>(&stage[px * LDT + c8 * 8]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    return;
+  }
+  if (STAGED) return;
   const bool interior = x0 + TC <= Wo;
   const int esz = p.out_bf16 ? 2 : 4;
   const bool pairs = ((p.Cout | p.ldo) & 1) == 0;  // lane pairs (n, n+1) are both valid or both invalid, rows stay 4-B aligned
@@ -175,8 +230,9 @@ template <int TM, int KS, int S, int NW> struct Geo {
   __host__ __device__ static constexpr int row_step() { return KS == 1 ? 1 : S; }  // patch rows per output row
 };
 
-template <int TM, int TN, int KS, int S, bool INB, int NW>
-__global__ __launch_bounds__(64 * NW) void conv_rows_bf16(RowsArgs p) {
+// (second launch bound = minimum waves per SIMD: the 64-channel bf16 tiles sit one register above the three-workgroup limit)
+template <int TM, int TN, int KS, int S, bool INB, int NW, bool STAGED>
+__global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3 : 1) void conv_rows_bf16(RowsArgs p) {
   using G = Geo<TM, KS, S, NW>;
   constexpr int NT = 64 * NW;
   constexpr int BN = TN * 32;
@@ -186,6 +242,7 @@ __global__ __launch_bounds__(64 * NW) void conv_rows_bf16(RowsArgs p) {
   constexpr int NWF = (KS * BN * 4 + NT - 1) / NT;        // 16-B weight pieces per thread per stage (KS taps x BN rows x 64 B)
   __shared__ __attribute__((aligned(16))) unsigned short Ps[G::NSLOT * LDP];
   __shared__ __attribute__((aligned(16))) unsigned short Ws[KS * BN * LDP];
+  static_assert(!STAGED || NW * stage_elems<TN>() <= G::NSLOT * LDP, "the bf16 epilogue's staging tiles reuse the patch LDS");
   __shared__ __attribute__((aligned(16))) float Sst[2 * MAXC];  // (mean, rstd) of the input channels of this image
 
   const int t = threadIdx.x;
@@ -363,7 +420,8 @@ __global__ __launch_bounds__(64 * NW) void conv_rows_bf16(RowsArgs p) {
   // pixel: lane pairs swap one value (DPP) so that the even lane owns channels (n, n+1) of pixel e and the odd lane the
   // same channels of pixel e+1 -- one 4-byte (bf16) / 8-byte (fp32) store per lane and register PAIR instead of a 2-byte
   // store per register (the scalar bf16 stores alone were a third of the 64-channel layers' time).
-  epilogue_rows<TM, TN, TN == 3>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, n0, tiles_x, tx, lane);
+  // (the loop above ended with a barrier: patch and weights are dead, the staging tiles reuse their LDS)
+  epilogue_rows<TM, TN, TN == 3, STAGED>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, n0, tiles_x, tx, lane, Ps + wm * stage_elems<TN>());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,7 +436,7 @@ constexpr int SNP = SPR * SPC;
 constexpr int SKW = 7 * 32;                         // K
 constexpr int SLW = SKW + 8;                        // LDS weight row stride (bf16): 464 B, conflict-free b128 reads
 
-template <int TN>
+template <int TN, bool STAGED>
 __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
   constexpr int TM = 2, BN = TN * 32;
   constexpr int NPL = (SNP + 255) / 256;
@@ -455,7 +513,9 @@ __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
     }
   }
 
-  epilogue_rows<TM, TN, true>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, 0, tiles_x, tx, lane);
+  __syncthreads();  // every wave is done with the patch / weights: Ws becomes the staging area
+  static_assert(4 * stage_elems<TN>() <= BN * SLW, "staging tiles fit the weight buffer");
+  epilogue_rows<TM, TN, true, STAGED>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, 0, tiles_x, tx, lane, Ws + wm * stage_elems<TN>());
 }
 
 }  // namespace
@@ -482,17 +542,25 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
   const bool n96 = Cout % 64 != 0 && Cout % 96 == 0;
   const int bn = n96 ? 96 : 64;
   // (64-channel tiles keep three workgroups per CU with bf16 tensors: measured 1.4x faster than 128-channel tiles at one per CU)
+  // bf16 output goes through the LDS-staged epilogue when the tensor allows 16-byte pieces (and the staging tiles fit the patch)
+  const bool st_ok = a.out_bf16 && Cout % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out & 15) == 0;
+#define LAUNCH2(TM_, TN_, KS_, S_, NW_, INB_)                                                                                       \
+  do {                                                                                                                             \
+    constexpr bool fits = NW_ * stage_elems<TN_>() <= Geo<TM_, KS_, S_, NW_>::NSLOT * LDP;                                          \
+    if (fits && st_ok) hipLaunchKernelGGL((conv_rows_bf16<TM_, TN_, KS_, S_, INB_, NW_, fits>), grid, dim3(64 * NW_), 0, stream, a); \
+    else hipLaunchKernelGGL((conv_rows_bf16<TM_, TN_, KS_, S_, INB_, NW_, false>), grid, dim3(64 * NW_), 0, stream, a);            \
+  } while (0)
 #define LAUNCH(TM_, KS_, S_, NW_)                                                                                                   \
   do {                                                                                                                             \
     const long long tiles = (long long)n * mvt_cdiv(Ho, NW_ * TM_) * mvt_cdiv(Wo, TC) * mvt_cdiv(Cout, bn);                        \
     MVT_REQUIRE(tiles < (1LL << 31));                                                                                              \
     const dim3 grid((unsigned)tiles);                                                                                              \
     if (n96) {                                                                                                                     \
-      if (a.in_bf16) hipLaunchKernelGGL((conv_rows_bf16<TM_, 3, KS_, S_, true, NW_>), grid, dim3(64 * NW_), 0, stream, a);         \
-      else hipLaunchKernelGGL((conv_rows_bf16<TM_, 3, KS_, S_, false, NW_>), grid, dim3(64 * NW_), 0, stream, a);                  \
+      if (a.in_bf16) LAUNCH2(TM_, 3, KS_, S_, NW_, true);                                                                          \
+      else LAUNCH2(TM_, 3, KS_, S_, NW_, false);                                                                                   \
     } else {                                                                                                                       \
-      if (a.in_bf16) hipLaunchKernelGGL((conv_rows_bf16<TM_, 2, KS_, S_, true, NW_>), grid, dim3(64 * NW_), 0, stream, a);         \
-      else hipLaunchKernelGGL((conv_rows_bf16<TM_, 2, KS_, S_, false, NW_>), grid, dim3(64 * NW_), 0, stream, a);                  \
+      if (a.in_bf16) LAUNCH2(TM_, 2, KS_, S_, NW_, true);                                                                          \
+      else LAUNCH2(TM_, 2, KS_, S_, NW_, false);                                                                                   \
     }                                                                                                                              \
   } while (0)
   static const int nw8 = getenv("MVT_ROWS_NW8") ? atoi(getenv("MVT_ROWS_NW8")) : 0;  // tuning override
@@ -502,6 +570,7 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
   else if (ksize == 3) LAUNCH(1, 3, 2, 4);   // the stride-2 patch is four times larger per output pixel: 4 x 32 pixel tiles
   else if (stride == 1) LAUNCH(2, 1, 1, 4);
   else LAUNCH(2, 1, 2, 4);
+#undef LAUNCH2
 #undef LAUNCH
   return mvt_launch_status();
 }
@@ -520,7 +589,13 @@ __attribute__((visibility("hidden"))) int mvt_detail_stem7x7_rows(const float* i
   a.out_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
   const long long tiles = (long long)n * mvt_cdiv(Ho, TR) * mvt_cdiv(Wo, TC);
   MVT_REQUIRE(tiles < (1LL << 31) && (long long)(TC + 8) * ldo * 4 < (1LL << 31));
-  if (Cout <= 32) hipLaunchKernelGGL((stem7x7_rows_bf16<1>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((stem7x7_rows_bf16<2>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  const bool st_ok = a.out_bf16 && Cout % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out & 15) == 0;
+  if (Cout <= 32) {
+    if (st_ok) hipLaunchKernelGGL((stem7x7_rows_bf16<1, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((stem7x7_rows_bf16<1, false>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  } else {
+    if (st_ok) hipLaunchKernelGGL((stem7x7_rows_bf16<2, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((stem7x7_rows_bf16<2, false>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  }
   return mvt_launch_status();
 }
