@@ -41,6 +41,7 @@ template <int NMB> struct Cfg {
   static constexpr int LDA = 296;                        // attention tile row stride (Ko = 288)
   static_assert(BM * LDA <= 2 * BM * LDH, "attention tile fits the H buffers");
 };
+constexpr int YLD = 40;   // bf16 row stride of the projection staging tile (32 columns + 8 pad)
 constexpr int FS = 512;   // elements per (32-row block, k-step) weight fragment: [64 lanes][8 bf16], see mvt_pack_frag_bf16
 
 struct BlockArgs {
@@ -426,6 +427,32 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
       gemm_wq<C / 16, NMB>(acc, wq, nrow_of(nb), nb + nbstep < nblocks ? nrow_of(nb + nbstep) : (chain ? chain : nrow_of(nb)), &Xs[r * LDX + 8 * h], LDX, 0);
+      if (nx.y_bf16 && nb * 32 + 31 < nx.N && (nx.ldy & 7) == 0 && ((uintptr_t)nx.y & 15) == 0) {
+        // bf16 projection output through a wave-private LDS tile (the H buffers are idle now): the accumulator layout (token on
+        // the lane) stores 8 bytes per lane into 32 different rows; staged, every lane stores 16 bytes and a row's 32 columns
+        // leave as one 64-B piece.
+        unsigned short* tile = &Hs[0][0] + wave * (NMB * 32 * YLD);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[mb][4 * g + e] + b1s[nb * 32 + 8 * g + 4 * h + e];
+            *reinterpret_cast<u32x2*>(&tile[(mb * 32 + r) * YLD + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, __builtin_convertvector(o, bf16x4));
+          }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        unsigned short* yb = reinterpret_cast<unsigned short*>(nx.y) + nb * 32;
+#pragma unroll
+        for (int k = 0; k < NMB * 2; ++k) {
+          const int pc = lane + 64 * k, row = pc >> 2, c = pc & 3;
+          const long long m = m0 + row;
+          if (m < p.M && m >= nx.row_lo && m < nx.row_hi)
+            *reinterpret_cast<u32x4*>(yb + m * (long long)nx.ldy + c * 8) = *reinterpret_cast<const u32x4*>(&tile[row * YLD + c * 8]);
+        }
+        continue;
+      }
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
         const long long m = m0 + mb * 32 + r;
