@@ -155,6 +155,10 @@ int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 whe
                                              launches cut over 4x more workgroups (deterministic partial sums) */,
                          void* stream);
 
+/* LayerNorm + projections only (x is read, never written): y_i = LayerNorm_i(x) . Wn_i^T + bn_i with the mvt_block_next
+ * descriptors of mvt_block_fused_bf16 -- the first q|k|v projection of an updater call. */
+int mvt_ln_proj_bf16(const float* x, int ldx, const mvt_block_next* next, int n_next, long long M, int C, void* stream);
+
 /* rgbs [V][T][3][H][W] (values 0..255) -> x [T_sel][V][H][W][4] = (2*(rgb/255)-1, 0) for frames
  * t0..t0+nt-1 (mvtracker.py:565-567 normalisation + channels-last repack). */
 int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream);

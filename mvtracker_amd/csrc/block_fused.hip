@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (MODE == 2) {  // x after the projection (pass 1) + b2 + the MLP partials, in chunk order
+      if (MODE == 2 && p.ws) {  // x after the projection (pass 1) + b2 + the MLP partials, in chunk order
         if (m < p.M) {
           const long long o = m * C + wave * 32 + 8 * g + 4 * h;
           xv = *reinterpret_cast<const f32x4*>(p.ws + o);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) xv[e] += p.b2[wave * 32 + 8 * g + 4 * h + e];
-      } else if (m < p.M) {
+      } else if (m < p.M) {  // (MODE 2 without a workspace = mvt_ln_proj_bf16: x is final and only read; ws / b2 are null there)
         xv = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
       }
 #pragma unroll
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += acc2[mb][4 * g + e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
   }
-  if (MODE == 0 || blockIdx.y == 0) store_x();
+  if (MODE == 0 || (p.ws && blockIdx.y == 0)) store_x();  // (never in the projection-only form: x is read-only there)
 
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
   bool have = tail_next;  // the queue already holds this wave's first block of the projection
@@ -542,5 +542,27 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const void* att, int att_
   } else {
     hipLaunchKernelGGL((block_fused_bf16<1, 0>), dim3((unsigned)mvt_cdiv(M, 32)), dim3(NT), 0, mvt_stream(stream), a);
   }
+  return mvt_launch_status();
+}
+
+// LayerNorm + projections only: y_i = LayerNorm_i(x) . Wn_i^T + bn_i (the first time-attention q|k|v of an updater call, which no
+// preceding block can produce): pass 2 of the split path without a workspace -- x is read, never written.
+extern "C" int mvt_ln_proj_bf16(const float* x, int ldx, const mvt_block_next* next, int n_next, long long M, int Cc, void* stream) {
+  MVT_REQUIRE(x && next && n_next >= 1 && n_next <= MVT_BLOCK_MAX_NEXT && M > 0 && Cc == C && ldx % 4 == 0 && ldx >= C);
+  MVT_REQUIRE((uintptr_t)x % 16 == 0);
+  BlockArgs a{};
+  a.x = const_cast<float*>(x); a.ldx = ldx; a.M = M; a.n_next = n_next; a.H = 4 * C; a.ws = nullptr;
+  int maxblk = 1;
+  for (int q = 0; q < n_next; ++q) {
+    const mvt_block_next& nx = next[q];
+    MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
+    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo) && (nx.y_bf16 == 0 || nx.y_bf16 == 1));
+    a.next[q] = nx;
+    if (nx.row_hi == 0) a.next[q].row_hi = M;
+    maxblk = (nx.N + 31) / 32 > maxblk ? (nx.N + 31) / 32 : maxblk;
+  }
+  hipLaunchKernelGGL((block_fused_bf16<1, 2>), dim3((unsigned)mvt_cdiv(M, 32), (unsigned)mvt_cdiv(maxblk, 8)), dim3(NT), 0, mvt_stream(stream),
+                     a);
   return mvt_launch_status();
 }

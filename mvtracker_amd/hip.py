@@ -51,6 +51,7 @@ SIGNATURES = {
     "mvt_tile_aabb": [P, LL, I, I, I, P, P],
     "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P, I, I, P],
     "mvt_knn_merge": [P, I, I, I, I, LL, P, P],
+    "mvt_ln_proj_bf16": [P, I, P, I, LL, I, P],
     "mvt_adapter_best_view": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mvt_knn_scan_levels": [I, P, P, I, I, I, I, I, I, I, P],
     "mvt_knn_merge_levels": [I, P, I, I, I, P],
@@ -192,6 +193,15 @@ def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw
                            nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)), 1 if nx["y"].dtype == torch.bfloat16 else 0)
     _call("mvt_block_fused_bf16", _ptr(x), ldx, _ptr(att), 1 if (att is not None and att.dtype == torch.bfloat16) else 0, ldatt, Ko, _ptr(wo), ldwo, _ptr(bo), _ptr(w1), ldw1, _ptr(b1), _ptr(w2),
           ldw2, _ptr(b2), H, C.cast(arr, C.c_void_p), len(nexts), M, Cc, _ptr(ws), _stream())
+
+
+def ln_proj_bf16(x, ldx, nexts, M, Cc):
+    """LayerNorm + projections of ``nexts`` (same dicts as ``block_fused_bf16``); x is only read."""
+    arr = (BlockNext * len(nexts))()
+    for i, nx in enumerate(nexts):
+        arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],
+                           nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)), 1 if nx["y"].dtype == torch.bfloat16 else 0)
+    _call("mvt_ln_proj_bf16", _ptr(x), ldx, C.cast(arr, C.c_void_p), len(nexts), M, Cc, _stream())
 
 
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):

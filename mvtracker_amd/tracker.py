@@ -394,9 +394,13 @@ class MVTracker(nn.Module):
         hs, ws = H // self.stride, W // self.stride
         C = self.latent_dim
         t1 = T if t1 is None else t1
-        fv = [torch.zeros(T, V, hs, ws, C, device=dev) if level0 is None else level0]
+        # (no memset of the 0.8 GB level-0 store: frames [t0, T) are written by the encoder before any window reads them --
+        #  later frames possibly on the second stream, ordered by events -- and frames before t0 are never read)
+        fv = [torch.empty(T, V, hs, ws, C, device=dev) if level0 is None else level0]
         for lvl in range(1, self.corr_n_levels):
-            fv.append(torch.zeros(T, V, hs >> lvl, ws >> lvl, C, device=dev))
+            fv.append(torch.empty(T, V, hs >> lvl, ws >> lvl, C, device=dev))
+        for f_ in fv[(1 if level0 is not None else 0):]:
+            f_[:t0].zero_()
         self.fill_frame_features({"fvec": fv}, rgbs, t0, t1, level0)
         kinv = torch.empty(V * T, 9, device=dev)
         einv = torch.empty(V * T, 12, device=dev)
@@ -563,7 +567,10 @@ class MVTracker(nn.Module):
         self._lin(pk, u + "input_transform", x, ldx, Mp, tok, h)
         hip.broadcast_rows(pk["virtual"], tok[Mp:], h, nv, S, h)
         pt, vt = tok[:Mp], tok[Mp:]
-        self._ln_lin(pk, f"{u}time_blocks.0.attn.qkv", tok, M, qkv, 3 * inner, xn)
+        if h == 256:  # LayerNorm + projection in one launch (the split path's second pass without a workspace)
+            hip.ln_proj_bf16(tok, h, [self._next(pk, f"{u}time_blocks.0.attn.qkv", qkv, 3 * inner)], M, h)
+        else:
+            self._ln_lin(pk, f"{u}time_blocks.0.attn.qkv", tok, M, qkv, 3 * inner, xn)
         for i in range(self.depth):
             tb, v2p = f"{u}time_blocks.{i}", f"{u}space_virtual2point_blocks.{i}"
             vs, p2v = f"{u}space_virtual_blocks.{i}", f"{u}space_point2virtual_blocks.{i}"

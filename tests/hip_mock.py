@@ -100,6 +100,16 @@ def block_fused_bf16(x, ldx, att, ldatt, Ko, wo, ldwo, bo, w1, ldw1, b1, w2, ldw
         _v(nx["y"], hi, nx["N"], nx["ldy"])[lo:hi] = (a @ Wn.t() + nx["b"][:nx["N"]])[lo:hi].to(nx["y"].dtype)
 
 
+def ln_proj_bf16(x, ldx, nexts, M, Cc):
+    xv = _v(x, M, Cc, ldx)
+    for nx in nexts:
+        Wn = _unfrag(nx["w"], nx["N"], Cc)
+        a = _bf(F.layer_norm(xv, (Cc,), nx.get("lnw"), nx.get("lnb"), nx["eps"]))
+        lo, hi = nx.get("rows", (0, 0))
+        hi = hi or M
+        _v(nx["y"], hi, nx["N"], nx["ldy"])[lo:hi] = (a @ Wn.t() + nx["b"][:nx["N"]])[lo:hi].to(nx["y"].dtype)
+
+
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
     xv = _v(x, M, Cc, ldx)
     W1 = torch.as_strided(w1, (H, ldw1), (ldw1, 1)).view(torch.bfloat16).float()[:, :Cc]
@@ -395,7 +405,7 @@ def install(monkeypatch):
     import sys
     from mvtracker_amd import hip
     me = sys.modules[__name__]
-    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
+    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 ln_proj_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
                  "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

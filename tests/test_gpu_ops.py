@@ -353,6 +353,27 @@ def test_block_fused_split_path(hip, M, n_next):
         assert torch.equal(a == 5.0, b == 5.0)
 
 
+@pytest.mark.parametrize("M", [13056, 100])
+def test_ln_proj_bf16(hip, M):
+    g = torch.Generator().manual_seed(M)
+    C, N = 256, 864
+    bf = lambda t: t.to(torch.bfloat16).double()
+    x = torch.randn(M, C, generator=g) * 1.3 + 0.1
+    w = torch.randn(N, C, generator=g) / 16
+    b = torch.randn(N, generator=g) * 0.1
+    hi = split(hip, G(pad_w(w)), False)[0]
+    fr = torch.empty((N + 31) // 32 * 32 * C, device=DEV, dtype=torch.int16)
+    hip.pack_frag_bf16(hi, hi.shape[1], N, C, fr)
+    xg = G(x)
+    for dt, tol in ((torch.float32, 6e-3), (torch.bfloat16, 1.2e-2)):
+        y = torch.full((M, N), 3.0, device=DEV, dtype=dt)
+        hip.ln_proj_bf16(xg, C, [dict(w=fr, ldw=C, b=G(b), N=N, y=y, ldy=N, eps=1e-6)], M, C)
+        torch.cuda.synchronize()
+        ref = bf(F.layer_norm(x.double(), (C,), None, None, 1e-6).float()) @ bf(w).t() + b.double()
+        assert rel_err(y.float(), ref) < tol
+    assert torch.equal(xg.cpu(), x)  # x is only read
+
+
 @pytest.mark.parametrize("M,cut", [(13056, 12288), (1000, 333), (200, 0)])
 def test_block_fused_row_ranges(hip, M, cut):
     """Three follow-up projections restricted to row ranges (one launch over point + virtual rows): rows outside a range
