@@ -4,7 +4,11 @@ TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Parity status: PINNED.  The
 below are checked in this container against the imported reference (tests/golden/make_golden.py
 generates tests/golden/*.npz from /root/reference; tests/test_oracle_golden.py re-checks the
 oracle against those files on every run).  The reference has no tests / golden vectors of its
-own for this path.
+own for this path.  Round 2 adds reference runs under
+``torch.autocast("cpu", dtype=torch.bfloat16)`` (tests/golden/make_golden_r2.py, the arithmetic of
+BASELINE config C3): run under the same autocast context this file is BIT-IDENTICAL to them
+(``knn_mode="cdist"``; 0.0 max difference on tracks and visibilities), including the reference's
+autocast quirks (bf16 point clouds, bf16 ``ffeats``).
 
 Every function cites the reference file:line it follows (paths relative to /root/reference).
 The code is a functional restatement over a flat ``weights`` dict that uses the reference's
@@ -594,13 +598,13 @@ def tracker_forward(W, cfg: TrackerConfig, rgbs: Tensor, depths: Tensor, query_p
             fmaps_seq, depths_seq, intrs_seq, extrs_seq = map(pad, (fmaps_seq, depths_seq, intrs_seq, extrs_seq))
         if p1 - p0 > 0:  # feature init by 1-NN in the frame's fused level-0 cloud, :607-645
             xyz, fvec = pointcloud_level(f_new, d_new, intrs[:, :, t0:t1], extrs[:, :, t0:t1], st, 0)
-            f_init = torch.zeros(1, p1 - p0, C)
+            f_init = torch.zeros(1, p1 - p0, C, dtype=f_new.dtype)  # :624-625 (bf16 under autocast)
             for t in range(t0, min(t1, T)):
                 m = qt_s[p0:p1] == t
                 if int(m.sum()) == 0:
                     continue
                 _, nn_idx = knn(1, xyz[t - t0][None], qxyz_s[0, p0:p1][m][None], knn_mode)
-                f_init[0, m] = fvec[t - t0][nn_idx[0, :, 0]].float()
+                f_init[0, m] = fvec[t - t0][nn_idx[0, :, 0]]
                 if trace is not None:
                     trace.setdefault("init_idx", []).append((t, nn_idx[0, :, 0].clone()))
             f_init = f_init[:, None].repeat(1, S, 1, 1)
@@ -726,6 +730,58 @@ def predictor_forward(W, cfg, rgbs, depths, query_points_3d, intrs, extrs, inter
     vis = res["vis_e"][:, :, :n]
     return {"traj_e": res["traj_e"][:, :, :n], "vis_e": vis > visibility_threshold, "vis_e_as_prob": vis,
             "vis_logits": res["vis_logits"][:, :, :n], "support_points": support, "intrs": intrs}
+
+
+def predictor_single_point_queries(depths, query_points_3d, intrs, extrs, support, local_grid_size=8, local_extent=50):
+    """Per-query model inputs of single_point mode (evaluation_predictor_3dpt.py:191-256): for query i the rows are
+    [query i ; local grid of every view around its projection, sampled at the query's own frame ; global support].
+    depths (1,V,T,1,H,W) etc. are the predictor's (already resized) tensors.  Returns a list of (1,M_i,4)."""
+    _, V, T, _, H, Wd = depths.shape
+    n = query_points_3d.shape[1]
+    kinv, einv = invert_cameras(intrs, extrs)
+    qt = query_points_3d[..., :1].long()
+    xyz = query_points_3d[..., 1:]
+    wh = torch.cat([xyz, torch.ones_like(xyz[..., :1])], -1)
+    cam = torch.einsum("BVTij,BNj->BVTNi", extrs, wh)  # :193-197
+    ph = torch.einsum("BVTij,BVTNj->BVTNi", intrs, cam)
+    pix = ph[..., :2] / ph[..., 2:]
+    pix = pix[torch.arange(1)[:, None, None], torch.arange(V)[None, :, None], qt[:, None, :, 0], torch.arange(n)[None, None, :]]
+    out = []
+    for i in range(n):
+        rows = [query_points_3d[:, i:i + 1]]
+        if local_grid_size > 0:
+            t = int(qt[0, i, 0])
+            for v in range(V):
+                g = grid_points(local_grid_size, (local_extent, local_extent), center=(pix[0, v, i, 1].item(), pix[0, v, i, 0].item()))
+                ok = (g[0, :, 0] >= 0) & (g[0, :, 0] < Wd) & (g[0, :, 1] >= 0) & (g[0, :, 1] < H)  # :228-233
+                if not bool(ok.any()):
+                    continue
+                g = g[:, ok]
+                z = bilinear_sample2d(depths[0, v, t][None], g[..., 0], g[..., 1]).permute(0, 2, 1)
+                world = _unproject(g, z, kinv[:, v, t], einv[:, v, t])
+                rows.append(torch.cat([torch.ones_like(world[:, :, :1]) * t, world], dim=2))
+        rows.append(support)
+        out.append(torch.cat(rows, dim=1))
+    return out
+
+
+def predictor_forward_single_point(W, cfg, rgbs, depths, query_points_3d, intrs, extrs, interp_shape=(384, 512),
+                                   visibility_threshold=0.5, grid_size=5, n_grids_per_view=1, local_grid_size=8, local_extent=50,
+                                   n_iters=6, knn_mode="exact"):
+    """EvaluationPredictor.forward, single_point mode (evaluation_predictor_3dpt.py:191-277, 410-414): one independent
+    forward per query; only track 0 of each forward is kept."""
+    n = query_points_3d.shape[1]
+    T = rgbs.shape[2]
+    rgbs, depths, intrs, support = predictor_prepare(rgbs, depths, query_points_3d, intrs, extrs, interp_shape, grid_size,
+                                                     n_grids_per_view)
+    qs = predictor_single_point_queries(depths, query_points_3d, intrs, extrs, support, local_grid_size, local_extent)
+    traj = torch.zeros(1, T, n, 3)
+    vis = torch.zeros(1, T, n)
+    for i, q in enumerate(qs):
+        res = tracker_forward(W, cfg, rgbs, depths, q, intrs, extrs, iters=n_iters, knn_mode=knn_mode)
+        traj[:, :, i] = res["traj_e"][:, :, 0]
+        vis[:, :, i] = res["vis_e"][:, :, 0]
+    return {"traj_e": traj, "vis_e": vis > visibility_threshold, "vis_e_as_prob": vis, "per_query_inputs": qs}
 
 
 def adapter_best_view(depths: Tensor, query_points: Tensor, intrs: Tensor, extrs: Tensor) -> Tensor:

@@ -168,3 +168,108 @@ def test_adapter_view_assignment(golden):
                            query_frames=(2, 5))
     bv = O.adapter_best_view(T(clip["depths"][0]), T(g["query_points"][0]), T(clip["intrs"][0]), T(clip["extrs"][0]))
     assert np.array_equal(bv.numpy(), g["best_view"])
+
+
+# ---------------------------------------------------------------------------------- round-2 fixtures (make_golden_r2.py)
+AC = lambda: torch.autocast("cpu", dtype=torch.bfloat16)  # noqa: E731
+
+
+def test_pyramid_bf16_autocast(golden):
+    """H2 quirk: under autocast the reference's point cloud itself is bf16 (pixel grid cast to the fmap dtype,
+    model_utils.py:467, then two bf16 einsums) -- the oracle under autocast reproduces it bit-for-bit."""
+    g = golden("pyramid_small_bf16")
+    fm = T(g["fmaps"]).bfloat16()
+    with AC():
+        for lvl in range(3):
+            xyz, fvec = O.pointcloud_level(fm, T(g["depths_strided"]), T(g["intrs"]), T(g["extrs"]), 4, lvl)
+            assert xyz.dtype == torch.bfloat16 and fvec.dtype == torch.bfloat16
+            assert np.array_equal(xyz.float().numpy(), g[f"xyz{lvl}"])
+            assert np.array_equal(fvec.float().numpy(), g[f"fvec{lvl}"])
+
+
+@pytest.mark.parametrize("mode", ["cdist", "exact"])
+def test_refine_window_bf16_autocast(golden, W, mode):
+    g = golden("refine_window_small_bf16")
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=12, H=128, W=128, N=12)
+    with torch.no_grad(), AC():
+        fm = O.encoder(W, 2 * (T(clip["rgbs"]).reshape(-1, 3, 128, 128) / 255.0) - 1).reshape(1, 2, 12, 128, 32, 32)
+        d = torch.nn.functional.interpolate(T(clip["depths"]).reshape(-1, 1, 128, 128), scale_factor=0.25, mode="nearest")
+        q = T(clip["query_points"])
+        n = q.shape[1]
+        preds, vis = O.refine_window(W, CFG, fm, d.reshape(1, 2, 12, 1, 32, 32), T(clip["intrs"]), T(clip["extrs"]),
+                                     q[:, None, :, 1:].repeat(1, 12, 1, 1), torch.full((1, 12, n, 1), 10.0),
+                                     torch.ones(1, 12, n, 1, dtype=torch.bool), T(g["feat_init"]).bfloat16(), iters=3, knn_mode=mode)
+    if mode == "cdist":  # the very same torch ops as the reference: bit-identical under autocast too
+        assert np.array_equal(torch.stack(preds).float().numpy(), g["coords_cdist"])
+        assert np.array_equal(vis.float().numpy(), g["vis_cdist"])
+    else:
+        close(torch.stack(preds).float(), g["coords_exact"], rtol=1e-4, atol=1e-5)
+        close(vis.float(), g["vis_exact"], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["e2e_tiny_bf16", "e2e_two_windows_bf16"])
+@pytest.mark.parametrize("mode", ["cdist", "exact"])
+def test_end_to_end_bf16_autocast(golden, W, name, mode):
+    """the oracle under CPU bf16 autocast against the REFERENCE under CPU bf16 autocast."""
+    g = golden(name)
+    kw = dict(seed=int(g["seed"]), V=int(g["V"]), T=int(g["T"]), H=int(g["H"]), W=int(g["W"]), N=int(g["N"]))
+    if "late_queries" in g.files:
+        kw.update(late_queries=bool(g["late_queries"]), query_frames=tuple(int(x) for x in g["query_frames"]))
+    clip = synth.make_clip(**kw)
+    a = [T(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
+    with torch.no_grad():
+        with AC():
+            r = O.tracker_forward(W, CFG, *a, iters=4, knn_mode=mode)
+        r32 = O.tracker_forward(W, CFG, *a, iters=4, knn_mode=mode)
+    ref = g["traj_" + mode]
+    rel = np.abs(r["traj_e"].float().numpy() - ref).max() / np.abs(ref).max()
+    verr = np.abs(r["vis_e"].float().numpy() - g["vis_" + mode]).max()
+    print(f"{name}/{mode}: oracle-autocast vs reference-autocast tracks {rel:.2e} vis {verr:.2e}")
+    if mode == "cdist":
+        assert rel == 0.0 and verr == 0.0  # same ops, same rounding points
+    else:
+        assert rel < 1e-4 and verr < 1e-3
+    # and the fp32 run recorded beside it (the distance autocast moves the reference itself)
+    assert np.abs(r32["traj_e"].numpy() - g["traj_fp32_" + mode]).max() / np.abs(ref).max() < 1e-4
+
+
+def test_predictor_single_point_local_grids(golden, W):
+    """single_point mode with local support grids (evaluation_predictor_3dpt.py:191-277): the per-query model inputs and
+    the kept tracks against the reference."""
+    g = golden("predictor_single_point")
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=12, H=128, W=128, N=3)
+    args = [T(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
+    args[2] = T(g["query_points"])
+    r = O.predictor_forward_single_point(W, CFG, *args, interp_shape=None, grid_size=2, local_grid_size=3, local_extent=20,
+                                         n_iters=2)
+    assert len(r["per_query_inputs"]) == int(g["n_calls"]) == 3
+    for i, q in enumerate(r["per_query_inputs"]):
+        ref_q = g[f"call{i}_query_points"]
+        assert q.shape == ref_q.shape
+        close(q, ref_q, rtol=1e-5, atol=1e-5)
+        assert np.array_equal(q[0, :, 0].long().numpy(), ref_q[0, :, 0].astype(np.int64))
+    ref = g["traj_e"]
+    assert np.abs(r["traj_e"].numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    close(r["vis_e_as_prob"], g["vis_e_as_prob"], rtol=0, atol=1e-3)
+
+
+def test_updateformer_hidden_384(golden):
+    """The class-default hidden_size=384 (mvtracker.py:101); the shipped config uses 256."""
+    g = golden("updateformer_h384")
+    cfg = O.TrackerConfig(hidden_size=384)
+    W384 = O.make_weights(cfg, seed=0)
+    close(O.update_former(W384, T(g["x"]), cfg), g["out"], rtol=1e-4, atol=1e-6)
+
+
+def window_corr_c128_inputs(g):
+    rng = np.random.default_rng(int(g["fmaps_seed"]))
+    fm = rng.standard_normal(tuple(int(x) for x in g["fmaps_shape"])).astype(np.float32)
+    assert abs(float(np.abs(fm).sum()) - float(g["fmaps_checksum"])) < 1e-3 * float(g["fmaps_checksum"])
+    return fm
+
+
+def test_window_corr_c128(golden):
+    g = golden("window_corr_c128")
+    fm = window_corr_c128_inputs(g)
+    pyr = O.window_corr_pyramid(T(fm), 4)
+    close(O.window_corr_sample(pyr, T(g["targets"]), T(g["coords"]), 4), g["out_r4"], rtol=1e-4, atol=1e-5)
