@@ -165,6 +165,10 @@ int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, 
 /* same from uint8 frames, the storage type of the sample files (demo.py:650, 922-929): the clip stays 1 byte per value in HBM
  * and over PCIe; (float)u8 is exact, so the result is bit-identical to converting first. */
 int mvt_rgb_u8_to_nhwc4(const unsigned char* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream);
+/* same for an arbitrary run of images numbered frame-major (image t * V + v = view v of frame t, the order of the frame store):
+ * images img0 .. img0+nimg-1 -> out [nimg][H][W][4].  The multi-GPU encoder split cuts the V*T images -- not frames -- evenly
+ * across ranks.  is_u8: rgbs holds bytes. */
+int mvt_rgb_images_to_nhwc4(const void* rgbs, int is_u8, float* out, int V, int T, int H, int W, long long img0, int nimg, void* stream);
 
 /* nearest-neighbour resize of [n][C][Hi][Wi] planes to [n][C][Ho][Wo] with torch's index rule
  * (evaluation_predictor_3dpt.py:76-81, F.interpolate(mode="nearest")). */

@@ -11,6 +11,7 @@ from . import hip
 
 
 @torch.no_grad()
+@hip.guarded
 def assign_views(depths: torch.Tensor, query_points: torch.Tensor, intrs: torch.Tensor, extrs: torch.Tensor, return_projections=False):
     """depths (1,V,T,1,H,W), query_points (1,N,4), intrs (1,V,T,3,3), extrs (1,V,T,3,4) -> best view per query (1,N) int64
     [, pixel xy (1,V,N,2), camera z (1,V,N,1)] -- `query_points_best_visibility_view` of the reference."""

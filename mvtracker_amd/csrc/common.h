@@ -43,10 +43,10 @@ __device__ __forceinline__ float mvt_act(float x, int act) {
 }
 
 // Activation tensors of the encoder are fp32 or, in bf16 mode, bf16 (MVT_IO_* flags).  Element offsets, fp32 values.
-__device__ __forceinline__ unsigned short mvt_bf16_bits(float v) {  // round to nearest even
-  const unsigned u = __float_as_uint(v);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
+// Plain cast (v_cvt_pk_bf16_f32, round to nearest even): a NaN stays a NaN.  Rounding by integer arithmetic on the f32 bits
+// turns some NaNs into 0 / inf (MI355X_MICROARCH.md, bf16 conversion pitfall), which would launder a NaN born in the bf16
+// encoder / updater before the deferred NaN guard (delta_split) sees it.
+__device__ __forceinline__ unsigned short mvt_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 __device__ __forceinline__ f32x4 load_act4(const float* base, long long off, int is_bf16) {
   if (!is_bf16) return *reinterpret_cast<const f32x4*>(base + off);
   const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);

@@ -7,14 +7,15 @@ namespace {
 
 template <typename TIN>
 __global__ void rgb_to_nhwc4_kernel(const TIN* __restrict__ rgbs, float* __restrict__ out, int V, int T, int H, int W,
-                                    int t0, int nt) {
+                                    long long img0, long long nimg) {
+  // images are numbered frame-major: image t * V + v is view v of frame t (the order of the frame store)
   const long long hw = (long long)H * W;
-  const long long total = (long long)nt * V * hw;
+  const long long total = nimg * hw;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     long long img = i / hw;
     long long pix = i - img * hw;
-    int tt = (int)(img / V), v = (int)(img - (long long)tt * V);
-    const TIN* src = rgbs + (((long long)v * T + (t0 + tt)) * 3) * hw + pix;
+    int tt = (int)((img0 + img) / V), v = (int)((img0 + img) - (long long)tt * V);
+    const TIN* src = rgbs + (((long long)v * T + tt) * 3) * hw + pix;
     f32x4 o;
     o[0] = 2.0f * ((float)src[0] / 255.0f) - 1.0f;
     o[1] = 2.0f * ((float)src[hw] / 255.0f) - 1.0f;
@@ -205,7 +206,22 @@ inline unsigned grid_for(long long total, int block = 256) {
 extern "C" int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream) {
   MVT_REQUIRE(rgbs && out && V > 0 && T > 0 && H > 0 && W > 0 && t0 >= 0 && nt > 0 && t0 + nt <= T);
   long long total = (long long)nt * V * H * W;
-  hipLaunchKernelGGL(rgb_to_nhwc4_kernel<float>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), rgbs, out, V, T, H, W, t0, nt);
+  hipLaunchKernelGGL(rgb_to_nhwc4_kernel<float>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), rgbs, out, V, T, H, W,
+                     (long long)t0 * V, (long long)nt * V);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_rgb_images_to_nhwc4(const void* rgbs, int is_u8, float* out, int V, int T, int H, int W, long long img0, int nimg,
+                                       void* stream) {
+  MVT_REQUIRE(rgbs && out && V > 0 && T > 0 && H > 0 && W > 0 && img0 >= 0 && nimg > 0 && img0 + nimg <= (long long)V * T);
+  MVT_REQUIRE(is_u8 == 0 || is_u8 == 1);
+  long long total = (long long)nimg * H * W;
+  if (is_u8)
+    hipLaunchKernelGGL(rgb_to_nhwc4_kernel<unsigned char>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream),
+                       (const unsigned char*)rgbs, out, V, T, H, W, img0, (long long)nimg);
+  else
+    hipLaunchKernelGGL(rgb_to_nhwc4_kernel<float>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), (const float*)rgbs, out, V, T,
+                       H, W, img0, (long long)nimg);
   return mvt_launch_status();
 }
 
@@ -213,7 +229,7 @@ extern "C" int mvt_rgb_u8_to_nhwc4(const unsigned char* rgbs, float* out, int V,
   MVT_REQUIRE(rgbs && out && V > 0 && T > 0 && H > 0 && W > 0 && t0 >= 0 && nt > 0 && t0 + nt <= T);
   long long total = (long long)nt * V * H * W;
   hipLaunchKernelGGL(rgb_to_nhwc4_kernel<unsigned char>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), rgbs, out, V, T, H, W,
-                     t0, nt);
+                     (long long)t0 * V, (long long)nt * V);
   return mvt_launch_status();
 }
 

@@ -7,7 +7,9 @@ provides device memory and the current HIP stream.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import functools
 import os
 
 import torch
@@ -40,6 +42,7 @@ SIGNATURES = {
     "mvt_mlp_fused_bf16": [P, I, P, I, P, P, I, P, LL, I, I, F, P],
     "mvt_rgb_to_nhwc4": [P, P, I, I, I, I, I, I, P],
     "mvt_rgb_u8_to_nhwc4": [P, P, I, I, I, I, I, I, P],
+    "mvt_rgb_images_to_nhwc4": [P, I, P, I, I, I, I, LL, I, P],
     "mvt_resize_nearest": [P, P, LL, I, I, I, I, P],
     "mvt_instnorm_stats": [P, I, P, P, I, LL, I, I, P],
     "mvt_instnorm_apply": [P, P, P, P, P, I, LL, I, I, P],
@@ -91,13 +94,47 @@ def _ptr(t):
 
 
 def require_device(t):
-    """The product path has no CPU implementation: refuse host tensors loudly."""
+    """The product path has no CPU implementation: refuse host tensors loudly; and the tensors' device must be the current
+    one (the launch stream is the current device's) -- entry points get there through ``device_guard``."""
     if not t.is_cuda:
         raise HipError("the MI355X tracker needs device tensors (got a CPU tensor); there is no CPU path")
+    if t.device.index != torch.cuda.current_device():
+        raise HipError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                       "launches go to the current device's stream (wrap the call in hip.device_guard(tensor))")
 
 
 def _stream():
+    """The launch stream: torch's current stream of the CURRENT device.  Every public entry point of the package runs
+    under ``device_guard`` of its tensors, so this is the stream of the device the pointers live on."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def device_guard(t):
+    """Context manager that makes ``t``'s device the current one (no-op for host tensors, which only the CPU host-logic
+    tests pass).  A model on cuda:1 called while cuda:0 is current would otherwise launch on device 0's stream with
+    device-1 pointers."""
+    if t is not None and t.is_cuda:
+        return torch.cuda.device(t.device)
+    return contextlib.nullcontext()
+
+
+def guarded(fn):
+    """Decorator for entry points whose first tensor argument fixes the device of the call."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t = next((a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor)), None)
+        if t is None:  # e.g. (store dict, ...) first: look one level into dicts / lists
+            for a in list(args) + list(kwargs.values()):
+                if isinstance(a, dict):
+                    a = list(a.values())
+                if isinstance(a, (list, tuple)):
+                    t = next((x for x in a if isinstance(x, torch.Tensor)), None) or next(
+                        (y for x in a if isinstance(x, (list, tuple)) for y in x if isinstance(y, torch.Tensor)), None)
+                    if t is not None:
+                        break
+        with device_guard(t):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _call(name, *args):
@@ -214,6 +251,12 @@ def rgb_to_nhwc4(rgbs, out, V, T, H, W, t0, nt):
         _call("mvt_rgb_u8_to_nhwc4", _ptr(rgbs), _ptr(out), V, T, H, W, t0, nt, _stream())
     else:
         _call("mvt_rgb_to_nhwc4", _ptr(_f32c(rgbs)), _ptr(out), V, T, H, W, t0, nt, _stream())
+
+
+def rgb_images_to_nhwc4(rgbs, out, V, T, H, W, img0, nimg):
+    """Images img0 .. img0+nimg-1 in frame-major numbering (t * V + v) of rgbs (V,T,3,H,W) fp32 or uint8 -> out (nimg,H,W,4)."""
+    assert rgbs.is_contiguous() and rgbs.dtype in (torch.uint8, torch.float32)
+    _call("mvt_rgb_images_to_nhwc4", _ptr(rgbs), 1 if rgbs.dtype == torch.uint8 else 0, _ptr(out), V, T, H, W, img0, nimg, _stream())
 
 
 def resize_nearest(x, out, planes, Hi, Wi, Ho, Wo):

@@ -5,9 +5,9 @@ Contract: the query set is partitioned into contiguous sh
 shard is an INDEPENDENT forward -- exactly what the reference does when it runs query subsets
 (evaluation_predictor_3dpt.py:191-277, demo.py:809-824); the 64 virtual tracks of the updater couple
 the tracks of one call, so a shard's result equals the reference run on that subset, not on the
-union.  The only data-path exchange happens once, before the refinement loop: the frames are split
-into contiguous blocks, each rank encodes its block and the level-0 feature maps are all-gathered
-(each rank then derives pyramid levels 1-3 and the point clouds locally).  No collective runs inside
+union.  The only data-path exchange happens once, before the refinement loop: the V x T images are cut
+evenly across the ranks, each rank encodes its run of images straight into its slot of the level-0 store and the slots are
+all-gathered in place (each rank then derives pyramid levels 1-3 and the point clouds locally).  No collective runs inside
 the refinement loop; the small outputs are all-gathered at the end when requested.
 """
 from __future__ import annotations
@@ -17,6 +17,8 @@ from typing import Optional
 
 import torch
 import torch.distributed as dist
+
+from . import hip
 
 
 class ShardedTracker:
@@ -43,7 +45,17 @@ class ShardedTracker:
             dist.all_gather(parts, local.contiguous(), group=self.group)
         return out
 
+    def _all_gather_in_place(self, out: torch.Tensor, rank: int, world: int) -> None:
+        """``out`` = world equal chunks along dim 0; this rank's chunk already holds its contribution."""
+        per = out.shape[0] // world
+        mine = out[rank * per:(rank + 1) * per]
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out, mine, group=self.group)  # in-place form: input aliases its slot of the output
+        else:
+            dist.all_gather(list(out.chunk(world, dim=0)), mine.clone(), group=self.group)
+
     @torch.no_grad()
+    @hip.guarded
     def __call__(self, rgbs, depths, query_points, intrs, extrs, iters=4, gather_output=True):
         world, rank = self._world()
         m = self.model
@@ -61,27 +73,37 @@ class ShardedTracker:
             d0, i0, e0 = f32(depths[0]), f32(intrs[0]), f32(extrs[0])
             hs, ws, C = H // m.stride, W // m.stride, m.latent_dim
             dev = rgbs.device
-            level0 = torch.empty(T, V, hs, ws, C, device=dev)
+            # Level-0 store [T][V][hs][ws][C] plus (world - 1) images of tail padding: an all-gather moves world equal
+            # chunks, so a block whose image count is not a multiple of world spills at most world - 1 images past its end --
+            # into the next block's frames (rewritten when that block is exchanged, later on the same or on the ordered side
+            # stream) or, for the last block, into the padding.
+            storage = torch.empty(T * V + world - 1, hs, ws, C, device=dev)
+            level0 = storage[:T * V].view(T, V, hs, ws, C)
             level0[:t0].zero_()  # (never read: no window starts before the first query frame)
 
             def exchange_block(f0, f1):
-                cnt = (f1 - f0 + world - 1) // world
-                lo, hi = min(f1, f0 + rank * cnt), min(f1, f0 + (rank + 1) * cnt)
-                # (rows past a rank's share are frames >= f1 of the last ranks: gathered but never copied, so no memset)
-                local = torch.empty(cnt, V, hs, ws, C, device=dev)
+                """Frames [f0, f1): the V * (f1 - f0) IMAGES are cut evenly across the ranks (a frame-granular split leaves
+                ranks idle as soon as the block has fewer frames than ranks: 12 frames on 8 GPUs); every rank encodes its
+                run of images straight into its chunk of the store and the chunks are all-gathered IN PLACE."""
+                n_img = (f1 - f0) * V
+                per = (n_img + world - 1) // world
+                lo, hi = min(n_img, rank * per), min(n_img, (rank + 1) * per)
+                base = f0 * V
+                dst = storage[base:base + world * per]
                 if hi > lo:
-                    m.encode_frames(r0, t0=lo, t1=hi, out=local, out_t0=lo)
-                gathered = self._all_gather(local, world)  # frames f0 .. f0 + world*cnt - 1
-                level0[f0:f1] = gathered[:f1 - f0]
+                    m.encode_images(r0, base + lo, base + hi, storage)
+                if hi - lo < per:  # the unused rows of a short (or empty) share: zeros travel, never uninitialised memory
+                    storage[base + rank * per + (hi - lo):base + (rank + 1) * per].zero_()
+                self._all_gather_in_place(dst, rank, world)
 
             # The first window only reads frames [t0, t0+S): exchange those first and let the rest of the clip be encoded
             # and all-gathered on a second stream while the first windows are refined (events order each window after
             # the frames it reads, exactly like the single-GPU encoder overlap).
             first_end = min(T, t0 + m.S)
-            overlap = m.overlap_encoder and first_end < T and dev.type == "cuda"
-            exchange_block(t0, first_end if overlap else T)
-            store = m.build_frame_store(r0, d0, i0, e0, t0=t0, level0=level0, t1=first_end if overlap else T)
-            if overlap:
+            two_blocks = m.overlap_encoder and first_end < T
+            exchange_block(t0, first_end if two_blocks else T)
+            store = m.build_frame_store(r0, d0, i0, e0, t0=t0, level0=level0, t1=first_end if two_blocks else T)
+            if two_blocks and dev.type == "cuda":
                 main = torch.cuda.current_stream(dev)
                 side = m._side_stream(dev)
                 side.wait_stream(main)
@@ -91,11 +113,16 @@ class ShardedTracker:
                     ev = torch.cuda.Event()
                     ev.record(side)
                 store["pending"] = [(first_end, ev)]
-                for t_ in (r0, level0):  # allocated on the main stream, last used on the side stream
+                for t_ in (r0, storage):  # allocated on the main stream, last used on the side stream
                     t_.record_stream(side)
+            elif two_blocks:  # host tensors (the gloo tests): the same two exchanges, in order
+                exchange_block(first_end, T)
+                m.fill_frame_features(store, r0, first_end, T, level0=level0)
         res = m(rgbs, depths, query_points[:, a:b], intrs, extrs, iters=iters, frame_store=store)
         if not gather_output:
-            return res
+            return res  # (the caller owns the deferred NaN check: model.check_finite())
+        if hasattr(m, "check_finite"):
+            m.check_finite()  # the outputs are gathered for the host: read the shard's NaN flag once (mvtracker.py:401-404)
         per = (N + world - 1) // world
         traj = torch.zeros(per, T, 3, device=rgbs.device)
         vis = torch.zeros(per, T, device=rgbs.device)

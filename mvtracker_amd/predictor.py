@@ -10,11 +10,14 @@ bookkeeping on device tensors.
 """
 from __future__ import annotations
 
+import logging
 from typing import Optional, Tuple
 
 import torch
 
 from . import hip
+
+log = logging.getLogger(__name__)
 
 
 def _bilinear_sample_depth(depth: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
@@ -96,6 +99,7 @@ class EvaluationPredictor(torch.nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------
     @torch.no_grad()
+    @hip.guarded
     def forward(
             self,
             rgbs,
@@ -156,6 +160,7 @@ class EvaluationPredictor(torch.nn.Module):
                     rows.append(self._support_rows(depths[0, v, t, 0], pix, kinv[v, t], einv[v, t], t))
             support = torch.cat(rows, 0)
 
+        nan_flags = []
         fwd = dict(intrs=intrs, extrs=extrs, iters=self.n_iters, save_debug_logs=save_debug_logs,
                    debug_logs_path=debug_logs_path, query_points_view=query_points_view, **kwargs)
         if self.single_point:  # :191-339, one forward per query with its local grids
@@ -189,9 +194,19 @@ class EvaluationPredictor(torch.nn.Module):
                 res = self.model(rgbs, depths=depths, query_points=q_i, **fwd)
                 traj_e[:, :, i] = res["traj_e"][:, :, 0]
                 vis_e[:, :, i] = res["vis_e"][:, :, 0]
+                nan_flags.append(getattr(self.model, "last_nan_flag", None))
         else:  # joint mode, :341-360
             q = torch.cat([query_points_3d[0], support], 0)[None]
             res = self.model(rgbs, depths=depths, query_points=q, **fwd)
             traj_e = res["traj_e"][:, :, :num_points, :]
             vis_e = res["vis_e"][:, :, :num_points]
+            nan_flags.append(getattr(self.model, "last_nan_flag", None))
+        # deferred NaN guard of the model (reference mvtracker.py:401-404 logs in the iteration where the NaN appears): the
+        # caller is about to copy the tracks to the host anyway, so one flag read here costs nothing
+        flags = [f for f in nan_flags if f is not None]
+        if flags and int(torch.stack([f.reshape(()) for f in flags]).max().item()) != 0:
+            log.error("Got NaN values in coords, perhaps the training exploded")
+            self.last_nan = True
+        else:
+            self.last_nan = False
         return {"traj_e": traj_e, "vis_e": vis_e > self.visibility_threshold, "vis_e_as_prob": vis_e}

@@ -74,19 +74,26 @@ def _render(intr, extr, t, H, W, rng, invalid_frac):
 
 
 def make_clip(seed: int, V: int, T: int, H: int, W: int, N: int, late_queries: bool = False,
-              invalid_frac: float = 0.0, query_frames: Sequence[int] = (3, 7, 13)) -> Dict[str, np.ndarray]:
+              invalid_frac: float = 0.0, query_frames: Sequence[int] = (3, 7, 13), frame_period: Optional[int] = None,
+              rgb_dtype=np.float32) -> Dict[str, np.ndarray]:
     """Seeded clip with the predictor's input layout (batch dim 1), all float32.
 
     rgbs (1,V,T,3,H,W) integer-valued in [0,255]; depths (1,V,T,1,H,W) metres; intrs (1,V,T,3,3);
     extrs (1,V,T,3,4); query_points (1,N,4) = (t, x, y, z) in world space.  With
-    ``late_queries`` a quarter of the queries start at a frame from ``query_frames``.
+    ``late_queries`` a quarter of the queries start at a frame from ``query_frames``.  ``frame_period`` renders only the
+    first ``frame_period`` frames and repeats them (long high-resolution clips for throughput / property tests);
+    ``rgb_dtype=np.uint8`` stores the (integer-valued) frames as bytes.
     """
     rng = np.random.default_rng(seed)
     intrs, extrs = make_cameras(V, T, H, W)
-    rgbs = np.zeros((V, T, 3, H, W), np.float32)
+    rgbs = np.zeros((V, T, 3, H, W), rgb_dtype)
     depths = np.zeros((V, T, 1, H, W), np.float32)
     for v in range(V):
         for t in range(T):
+            if frame_period is not None and t >= frame_period:
+                rgbs[v, t] = rgbs[v, t % frame_period]
+                depths[v, t] = depths[v, t % frame_period]
+                continue
             rgb, d = _render(intrs[v, t], extrs[v, t], t, H, W, rng, invalid_frac)
             rgbs[v, t] = rgb
             depths[v, t, 0] = d

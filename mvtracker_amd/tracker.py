@@ -48,6 +48,16 @@ def _round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
 
+class _Shifted:
+    """View of a tensor whose row ``i`` is ``base[i - shift]`` (slice access only)."""
+
+    def __init__(self, base, shift):
+        self.base, self.shift = base, shift
+
+    def __getitem__(self, sl):
+        return self.base[sl.start - self.shift:sl.stop - self.shift]
+
+
 class MVTracker(nn.Module):
     def __init__(
             self,
@@ -348,20 +358,28 @@ class MVTracker(nn.Module):
             self._inorm(y, n, hs * ws, 2 * C, st=st)
             self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C)
 
+    @hip.guarded
+    def encode_images(self, rgbs, i0, i1, out, images_per_chunk=16):
+        """Encode images [i0, i1) of rgbs (V,T,3,H,W) in [0,255] -- images numbered frame-major, t * V + v, the order of the
+        frame store -- into ``out`` (>= i1 images, H/4, W/4, C): image i lands in out[i]."""
+        V, T, _, H, W = rgbs.shape
+        pk = self._pack(rgbs.device)
+        for a in range(i0, i1, images_per_chunk):
+            n = min(images_per_chunk, i1 - a)
+            x4 = torch.empty(n, H, W, 4, device=rgbs.device)
+            hip.rgb_images_to_nhwc4(rgbs, x4, V, T, H, W, a, n)
+            self._encode(pk, x4, n, H, W, out[a:a + n])
+
     def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16, out=None, out_t0=0):
         """rgbs (V,T,3,H,W) in [0,255] -> level-0 features (T,V,H/4,W/4,C); frames outside [t0,t1) are left zero
         (or untouched when the result goes into ``out``, whose first row is frame ``out_t0``)."""
         V, T, _, H, W = rgbs.shape
         t1 = T if t1 is None else t1
-        pk = self._pack(rgbs.device)
         hs, ws = H // self.stride, W // self.stride
         F0 = out if out is not None else torch.zeros(T, V, hs, ws, self.latent_dim, device=rgbs.device)
-        step = max(1, images_per_chunk // V)
-        for a in range(t0, t1, step):
-            nt = min(step, t1 - a)
-            x4 = torch.empty(nt * V, H, W, 4, device=rgbs.device)
-            hip.rgb_to_nhwc4(rgbs, x4, V, T, H, W, a, nt)
-            self._encode(pk, x4, nt * V, H, W, F0[a - out_t0:a - out_t0 + nt])
+        flat = F0.view(-1, hs, ws, self.latent_dim)
+        # (whole frames per chunk, as before: the chunk boundaries do not change any result, only the launch shapes)
+        self.encode_images(rgbs, t0 * V, t1 * V, _Shifted(flat, out_t0 * V), images_per_chunk=max(1, images_per_chunk // V) * V)
         return F0
 
     # ------------------------------------------------------------------ frame store (model_utils.py:420-482)
@@ -371,6 +389,7 @@ class MVTracker(nn.Module):
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
 
+    @hip.guarded
     def fill_frame_features(self, store, rgbs, a, b, level0=None):
         """Encode frames [a, b) into the store's feature pyramid (everything else in the store is geometry)."""
         V, T, _, H, W = rgbs.shape
@@ -382,6 +401,7 @@ class MVTracker(nn.Module):
             h, w = hs >> (lvl - 1), ws >> (lvl - 1)
             hip.avgpool2(fv[lvl - 1][a:b], fv[lvl][a:b], (b - a) * V, h, w, self.latent_dim)
 
+    @hip.guarded
     def build_frame_store(self, rgbs, depths, intrs, extrs, t0=0, level0=None, t1=None):
         """Features and world-space points of every pyramid level, frame-major.
 
@@ -606,6 +626,7 @@ class MVTracker(nn.Module):
         self._lin(pk, u + "flow_head.2", h1, ldh, Mp, h2, ldh, hip.ACT_RELU)
         self._lin(pk, u + "flow_head.4", h2, ldh, Mp, delta, ldd)
 
+    @hip.guarded
     def update_former(self, x):
         """EfficientUpdateFormer.forward on tokens x (1,N,S,D) -> (1,N,S,3+C) (test / parity entry)."""
         _, n, S, D = x.shape
@@ -620,6 +641,7 @@ class MVTracker(nn.Module):
         return delta[:, :self.out_dim].reshape(1, n, S, self.out_dim)
 
     # ------------------------------------------------------------------ one window (mvtracker.py:244-410)
+    @hip.guarded
     def refine_window(self, store, frame0, coords, vis_init, track_mask, feat_init, iters=4, nan_flag=None, trace=None):
         """Iterative refinement of one window.
 
@@ -687,6 +709,7 @@ class MVTracker(nn.Module):
 
     # ------------------------------------------------------------------ forward (mvtracker.py:412-732)
     @torch.no_grad()
+    @hip.guarded
     def forward(
             self,
             rgbs,

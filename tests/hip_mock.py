@@ -177,6 +177,14 @@ def rgb_to_nhwc4(rgbs, out, V, T, H, W, t0, nt):
     o[..., 3] = 0
 
 
+def rgb_images_to_nhwc4(rgbs, out, V, T, H, W, img0, nimg):
+    o = torch.as_strided(out, (nimg, H, W, 4), (H * W * 4, W * 4, 4, 1))
+    for i in range(nimg):
+        t, v = divmod(img0 + i, V)
+        o[i, ..., :3] = (2 * (rgbs[v, t].float() / 255.0) - 1.0).permute(1, 2, 0)
+        o[i, ..., 3] = 0
+
+
 def resize_nearest(x, out, planes, Hi, Wi, Ho, Wo):
     y = F.interpolate(x.reshape(1, planes, Hi, Wi), (Ho, Wo), mode="nearest")
     out.reshape(-1)[:planes * Ho * Wo].copy_(y.reshape(-1))
@@ -405,7 +413,7 @@ def install(monkeypatch):
     import sys
     from mvtracker_amd import hip
     me = sys.modules[__name__]
-    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 ln_proj_bf16 mlp_fused_bf16 rgb_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
+    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 ln_proj_bf16 mlp_fused_bf16 rgb_to_nhwc4 rgb_images_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
                  "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

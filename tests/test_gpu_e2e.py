@@ -145,11 +145,15 @@ def test_forward_vs_oracle_logits_and_late_queries(model, W):
     ref = ro["traj_e"]
     rel = ((r["traj_e"].cpu() - ref).abs().max() / ref.abs().max()).item()
     verr = (model.last_vis_logits.cpu() - ro["vis_logits"]).abs().max().item()
-    print(f"late-query clip: first neighbour flip {first_flip}, tracks rel {rel:.2e}, vis logits {verr:.2e}")
-    if first_flip is None:
-        assert rel < 1e-4 and verr < 1e-3, (rel, verr)
-    else:
-        assert rel < 5e-3 and verr < 0.5, (rel, verr)  # bounded divergence after a flip
+    # error relative to how far the tracks MOVE (the scene is ~4 m across, the seeded model moves a track ~0.2 m per clip)
+    q0 = args_of(clip)[2][0, :, 1:]
+    disp = (ref[0] - q0[None]).abs().max().item()
+    rel_disp = (r["traj_e"].cpu() - ref).abs().max().item() / disp
+    print(f"late-query clip: first neighbour flip {first_flip}, tracks rel {rel:.2e} (of the displacement {disp:.3f} m: {rel_disp:.2e}), "
+          f"vis logits {verr:.2e}")
+    assert first_flip is None, f"seed 57 is expected to be flip-free (DESIGN.md section 2), first flip at {first_flip}"
+    assert rel < 1e-4 and verr < 1e-3, (rel, verr)
+    assert rel_disp < 2e-3, rel_disp
 
 
 def test_predictor_golden(model, golden):
@@ -329,3 +333,238 @@ def test_world_to_pixel_golden(golden):
     assert (pix.cpu() - T(g["pix"])).abs().max() < 1e-3 and (z.cpu() - T(g["z"])).abs().max() < 1e-5
     t2 = project_tracks(T(g["world"]).to(DEV)[None], T(g["intrs"]).to(DEV)[None, None], T(g["extrs"]).to(DEV)[None, None])
     assert tuple(t2.shape) == (1, 1, 4, 9, 2) and torch.equal(t2[0, 0], pix)
+
+
+# ------------------------------------------------------------------------------------------------ round 2
+def _with_precision(model, prec):
+    class _P:
+        def __enter__(self_):
+            self_.old = model.precision
+            model.precision = prec
+
+        def __exit__(self_, *a):
+            model.precision = self_.old
+    return _P()
+
+
+@pytest.mark.parametrize("name", ["e2e_tiny_bf16", "e2e_two_windows_bf16"])
+def test_forward_bf16_vs_reference_autocast(model, golden, name):
+    """bf16 mode against the REFERENCE run under torch.autocast(cpu, bfloat16) (fixtures of make_golden_r2.py).
+
+    Two bf16 implementations cannot agree bit-wise (different rounding points: the reference rounds every conv / linear /
+    einsum output to bf16 -- including the unprojected point cloud, H2 -- this path keeps fp32 accumulators, fp32 point
+    clouds and fp32 kNN).  The fixture carries the reference's fp32 result beside its autocast result, so the bar is set by
+    the reference itself: d_ref = |reference_autocast - reference_fp32| is what bf16 arithmetic costs the reference;
+    the product in bf16 mode must be (a) at least as close to the fp32 reference as the autocast reference is and
+    (b) within 2 x d_ref of the autocast reference (triangle inequality)."""
+    g = golden(name)
+    clip = clip_from_golden(g)
+    with _with_precision(model, "bf16"):
+        r = model(*args_of(clip, DEV), iters=4)
+        torch.cuda.synchronize()
+        model.check_finite()
+    got, gv = r["traj_e"].cpu().numpy(), r["vis_e"].cpu().numpy()
+    ref32, refbf = g["traj_fp32_exact"], g["traj_exact"]
+    v32, vbf = g["vis_fp32_exact"], g["vis_exact"]
+    sc = np.abs(ref32).max()
+    d_ref, dv_ref = np.abs(refbf - ref32).max() / sc, np.abs(vbf - v32).max()
+    e32, ev32 = np.abs(got - ref32).max() / sc, np.abs(gv - v32).max()
+    ebf, evbf = np.abs(got - refbf).max() / sc, np.abs(gv - vbf).max()
+    print(f"{name}: reference autocast vs fp32: tracks {d_ref:.2e} vis {dv_ref:.2e} | product bf16 vs reference fp32: {e32:.2e} / {ev32:.2e}"
+          f" | product bf16 vs reference autocast: {ebf:.2e} / {evbf:.2e}")
+    assert e32 <= max(d_ref, 1e-4) and ev32 <= max(dv_ref, 1e-3), (e32, d_ref, ev32, dv_ref)
+    assert ebf <= 2 * d_ref and evbf <= 2 * dv_ref, (ebf, d_ref, evbf, dv_ref)
+
+
+def _check_sampled_rows(model, store, frame0, coords, feats, n_sample=64, seed=0, fcorr_tol=5e-5):
+    """Teacher-forced first refinement iteration at full size: run ONE iteration of the window on the device store, then for
+    ``n_sample`` tracks compare the kNN indices of every level (bit-exact) and the 256 correlation features per frame with the
+    oracle evaluated on the SAME store contents (copied to the host)."""
+    n, S = coords.shape[:2]
+    T_ = store["T"]
+    tr = {}
+    model.refine_window(store, frame0, coords, torch.full((n, S), 10.0, device=DEV), torch.ones(n, S, device=DEV), feats, iters=1, trace=tr)
+    torch.cuda.synchronize()
+    sample = torch.randperm(n, generator=torch.Generator().manual_seed(seed))[:n_sample]
+    frames = [min(frame0 + s, T_ - 1) for s in range(S)]
+    c = coords[sample].cpu().permute(1, 0, 2)          # (S, m, 3)
+    f = feats[sample].cpu().float().permute(1, 0, 2)   # (S, m, C)
+    worst = 0.0
+    for lvl in range(model.corr_n_levels):
+        xyz = store["xyz"][lvl][frames].reshape(S, -1, 4)[..., :3].cpu()
+        fvec = store["fvec"][lvl][frames].reshape(S, xyz.shape[1], -1).float().cpu()
+        o, idx = O.corr_sample(xyz, fvec, f, c, k=model.corr_neighbors, knn_mode="exact", return_idx=True)
+        got_idx = tr["knn_idx"][0][lvl][sample].cpu().long().permute(1, 0, 2)
+        assert torch.equal(got_idx, idx), f"kNN indices differ at level {lvl}"
+        K = model.corr_neighbors
+        got = tr["fcorrs"][0][sample].cpu().permute(1, 0, 2)[..., lvl * K * 4:(lvl + 1) * K * 4].reshape(S, n_sample, K, 4)
+        worst = max(worst, (got - o).abs().max().item())
+    assert worst < fcorr_tol, worst
+    return worst
+
+
+def _query_state(model, a, store, t=0):
+    """coords (n,S,3) and 1-NN initial features (n,S,C) of the queries that start at frame ``t`` (as MVTracker.forward does)."""
+    q = a[2][0]
+    sel = q[:, 0].long() == t
+    xyz = q[sel, 1:].contiguous()
+    n = xyz.shape[0]
+    from mvtracker_amd import hip
+    P0 = store["P"][0]
+    ns = model._nseg(P0, 1)
+    keys = torch.empty(n * ns, device=DEV, dtype=torch.int64)
+    feat = torch.empty(n, model.latent_dim, device=DEV)
+    hip.knn_scan(store["xyz"][0], P0, xyz, n, 1, t, 0, store["T"], 1, ns, keys, box=store["box"][0], grid=store["tile_grid"][0])
+    hip.knn1_gather(store["fvec"][0], P0, model.latent_dim, keys, n, ns, t, feat)
+    return xyz[:, None, :].repeat(1, model.S, 1), feat[:, None, :].repeat(1, model.S, 1).contiguous()
+
+
+def test_c3_bf16_full_size(model):
+    """BASELINE config C3 in ITS dtype: 4 views x 24 frames x 512^2, 1024 queries, bf16.  Size-independent properties (finite,
+    bit-deterministic, shard = independent forward, untouched frames before a late query, track at its query frame within the
+    refinement deltas) plus the teacher-forced sampled-row check of kNN / correlation against the oracle on the same store."""
+    clip = synth.make_clip(7, V=4, T=24, H=512, W=512, N=1024, late_queries=True)
+    a = args_of(clip, DEV)
+    with _with_precision(model, "bf16"):
+        r1 = model(*a, iters=4)
+        t1, v1 = r1["traj_e"].clone(), r1["vis_e"].clone()
+        model.check_finite()
+        assert t1.shape == (1, 24, 1024, 3) and bool(torch.isfinite(t1).all()) and bool(torch.isfinite(v1).all())
+        assert float(v1.min()) >= 0.0 and float(v1.max()) <= 1.0
+        r2 = model(*a, iters=4)
+        assert torch.equal(t1, r2["traj_e"]) and torch.equal(v1, r2["vis_e"])  # no atomics on the data path
+        sub = a[2][:, 100:356].clone()
+        r3 = model(a[0], a[1], sub, a[3], a[4], iters=4)["traj_e"].clone()
+        assert torch.equal(r3, model(a[0], a[1], sub, a[3], a[4], iters=4)["traj_e"])
+        q = a[2][0]
+        qt = q[:, 0].long()
+        late = torch.nonzero(qt == 13)[:, 0]
+        assert len(late) > 0 and float(t1[0, :6, late].abs().max()) == 0.0  # t=13 enters at the window starting at frame 6
+        at_q = t1[0, qt, torch.arange(1024, device=DEV)]
+        assert float((at_q - q[:, 1:]).abs().max()) < 0.25  # a track stays near its query at the query frame
+        store = model.build_frame_store(a[0][0], a[1][0], a[3][0], a[4][0])
+        coords, feats = _query_state(model, a, store, 0)
+        w = _check_sampled_rows(model, store, 0, coords, feats)
+        print(f"C3 bf16: sampled fcorr rows max abs err {w:.2e}")
+
+
+def test_c2_full_size_fp32_invalid_depth(model, W):
+    """BASELINE config C2: 3 views x 24 frames x 384x512, 512 queries, fp32, 2 % invalid depth (zero-depth pixels collapse onto
+    the camera centre: dense equidistant-candidate clusters).  Properties + sampled rows against the oracle on the same store."""
+    clip = synth.make_clip(11, V=3, T=24, H=384, W=512, N=512, late_queries=True, invalid_frac=0.02)
+    a = args_of(clip, DEV)
+    with _with_precision(model, "fp32"):
+        r1 = model(*a, iters=4)
+        t1 = r1["traj_e"].clone()
+        model.check_finite()
+        assert t1.shape == (1, 24, 512, 3) and bool(torch.isfinite(t1).all())
+        assert torch.equal(t1, model(*a, iters=4)["traj_e"])
+        store = model.build_frame_store(a[0][0], a[1][0], a[3][0], a[4][0])
+        # the store itself against the oracle for two frames (encoder + pyramid + unprojection at 384x512, invalid depth)
+        rgb = a[0][0, :, :2].cpu()
+        fm = O.encoder(W, (2 * (rgb / 255.0) - 1).reshape(-1, 3, 384, 512)).reshape(1, 3, 2, 128, 96, 128)
+        d = torch.nn.functional.interpolate(a[1][0, :, :2].cpu().reshape(-1, 1, 384, 512), scale_factor=0.25, mode="nearest")
+        for lvl in range(4):
+            xyz, fvec = O.pointcloud_level(fm, d.reshape(1, 3, 2, 1, 96, 128), a[3][:, :, :2].cpu(), a[4][:, :, :2].cpu(), 4, lvl)
+            assert (store["xyz"][lvl][:2].reshape(2, -1, 4)[..., :3].cpu() - xyz).abs().max() < 2e-5
+            e = (store["fvec"][lvl][:2].reshape(2, xyz.shape[1], 128).float().cpu() - fvec).abs().max() / fvec.abs().max()
+            assert e < 5e-5, (lvl, e)
+        coords, feats = _query_state(model, a, store, 0)
+        _check_sampled_rows(model, store, 0, coords, feats)
+        coords7, feats7 = _query_state(model, a, store, 7)  # late queries, a window that starts mid-clip
+        if coords7.shape[0] >= 16:
+            _check_sampled_rows(model, store, 6, coords7, feats7, n_sample=16)
+
+
+def test_c5_shard_720p_bf16(model):
+    """One GPU's share of BASELINE config C5: 6 views x 64 frames x 720x1280, 512 queries, bf16, 10 sliding windows.  The feature
+    pyramid is 180x320 -> 90x160 -> 45x80 -> 22x40: an odd level whose last row avgpool2 / the nearest depth subsample drop, and
+    levels that are not multiples of 8 (linear kNN tiles).  uint8 frames (1 GB instead of 4 GB); 4 rendered frames per view,
+    repeated.  Properties + sampled rows against the oracle on the same store (levels 2 and 3 are the odd ones)."""
+    clip = synth.make_clip(13, V=6, T=64, H=720, W=1280, N=512, late_queries=True, query_frames=(3, 7, 13, 30, 45), frame_period=4,
+                           rgb_dtype=np.uint8)
+    a = args_of(clip, DEV)
+    with _with_precision(model, "bf16"):
+        r1 = model(*a, iters=4)
+        t1 = r1["traj_e"].clone()
+        model.check_finite()
+        assert len(model.last_windows) == 10 and t1.shape == (1, 64, 512, 3) and bool(torch.isfinite(t1).all())
+        assert torch.equal(t1, model(*a, iters=4)["traj_e"])
+        store = model.build_frame_store(a[0][0], a[1][0], a[3][0], a[4][0], t1=12)
+        assert [tuple(x.shape[2:4]) for x in store["xyz"]] == [(180, 320), (90, 160), (45, 80), (22, 40)]
+        coords, feats = _query_state(model, a, store, 0)
+        _check_sampled_rows(model, store, 0, coords, feats, n_sample=32)
+        del store
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_odd_level_180x320(model, W, prec):
+    """180x320 images: 45x80 features -> 22x40 -> 11x20 -> 5x10: two odd levels whose last row is dropped by the pooling
+    (model_utils.py:436-444) -- against the oracle end to end (fp32) / against the fp32 run (bf16)."""
+    clip = synth.make_clip(17, V=2, T=12, H=180, W=320, N=14)
+    a = args_of(clip, DEV)
+    with _with_precision(model, "fp32"):
+        tr = []
+        t32 = model(*a, iters=2, trace=tr)["traj_e"].clone()
+    if prec == "fp32":
+        otr = {}
+        ro = O.tracker_forward(W, CFG, *args_of(clip), iters=2, knn_mode="exact", trace=otr)
+        for l in range(4):
+            assert torch.equal(tr[0]["knn_idx"][0][l].cpu().long(), otr["windows"][0]["knn_idx"][l].permute(1, 0, 2)), l
+        rel = ((t32.cpu() - ro["traj_e"]).abs().max() / ro["traj_e"].abs().max()).item()
+        assert rel < 1e-4, rel
+        assert (model.last_vis_logits.cpu() - ro["vis_logits"]).abs().max().item() < 1e-3
+    else:
+        with _with_precision(model, "bf16"):
+            rb = model(*a, iters=2)
+            model.check_finite()
+        assert ((rb["traj_e"] - t32).abs().max() / t32.abs().max()).item() < 2e-2
+
+
+def test_predictor_single_point_local_grids_golden(model, golden):
+    """single_point mode WITH local support grids against the reference-generated fixture (evaluation_predictor_3dpt.py:191-277)."""
+    from mvtracker_amd.predictor import EvaluationPredictor
+    g = golden("predictor_single_point")
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=12, H=128, W=128, N=3)
+    a = args_of(clip, DEV)
+    a[2] = T(g["query_points"]).to(DEV)
+    pred = EvaluationPredictor(model, interp_shape=None, grid_size=2, local_grid_size=3, local_extent=20, single_point=True, n_iters=2)
+    calls = []
+    orig = model.forward
+
+    def spy(*args, **kw):
+        calls.append(kw["query_points"].clone())
+        return orig(*args, **kw)
+
+    model.forward = spy
+    try:
+        r = pred(rgbs=a[0], depths=a[1], query_points_3d=a[2], intrs=a[3], extrs=a[4])
+    finally:
+        model.forward = orig
+    assert len(calls) == int(g["n_calls"])
+    for i, q in enumerate(calls):
+        ref_q = g[f"call{i}_query_points"]
+        assert tuple(q.shape) == ref_q.shape, (i, q.shape, ref_q.shape)
+        assert np.abs(q.cpu().numpy() - ref_q).max() < 1e-4
+    ref = g["traj_e"]
+    assert np.abs(r["traj_e"].cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    assert np.abs(r["vis_e_as_prob"].cpu().numpy() - g["vis_e_as_prob"]).max() < 1e-3
+    assert r["vis_e"].dtype == torch.bool
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16x3", 5e-5), ("bf16", 3e-2)])
+def test_updateformer_hidden_384_golden(golden, prec, tol):
+    """The class-default hidden_size=384 (generic, unfused updater path) against the reference fixture."""
+    from mvtracker_amd.tracker import MVTracker
+    g = golden("updateformer_h384")
+    m = MVTracker(hidden_size=384).eval()
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m.to(DEV)
+    m.precision = prec
+    out = m.update_former(T(g["x"]).to(DEV))
+    torch.cuda.synchronize()
+    ref = g["out"]
+    err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < tol, err

@@ -969,3 +969,66 @@ def test_delta_split_rowdot_broadcast(hip):
     xb = torch.zeros(64 * 12, 256, device=DEV)
     hip.broadcast_rows(G(v), xb, 256, 64, 12, 256)
     assert torch.equal(xb.cpu().reshape(64, 12, 256), v[:, None].expand(64, 12, 256))
+
+
+# ----------------------------------------------------------------------------------------- round 2: window corr at C=128
+def _window_corr_all_levels(hip, pyr, tg, cd, r):
+    """pyr: list of (BS,C,h,w) cpu maps; tg (BS,N,C); cd (BS,N,2) -> (BS,N,L*(2r+1)^2) device tensor."""
+    BS, N, C = tg.shape
+    D = (2 * r + 1) ** 2
+    L = len(pyr)
+    out = torch.zeros(BS, N, L * D, device=DEV)
+    tg_d, cd_d = G(tg), G(cd)
+    for lvl, f in enumerate(pyr):
+        h, w = f.shape[-2:]
+        hip.window_corr(G(f.permute(0, 2, 3, 1)), tg_d, cd_d, out, BS, N, C, h, w, lvl, r, L * D, lvl * D)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_window_corr_c128_golden(hip, golden):
+    """The C=128 instantiation (the channel count of config C3) against a reference-generated fixture: 4 levels, r=4."""
+    g = golden("window_corr_c128")
+    rng = np.random.default_rng(int(g["fmaps_seed"]))
+    fm = T(rng.standard_normal(tuple(int(x) for x in g["fmaps_shape"])).astype(np.float32))  # (1,2,128,32,48)
+    tg, cd = T(g["targets"]), T(g["coords"])
+    pyr = [f[0] for f in O.window_corr_pyramid(fm, 4)]
+    out = _window_corr_all_levels(hip, pyr, tg[0], cd[0], 4)
+    ref = g["out_r4"][0]
+    assert out.shape == ref.shape
+    assert np.abs(out.cpu().numpy() - ref).max() < 3e-5
+
+
+def test_window_corr_c3_shape_sampled_rows(hip):
+    """a7' at its real shape (S=12 frames, N=1024 tracks, 128x128 maps, C=128, r=4, 4 levels = 324 outputs per unit):
+    64 sampled tracks x 12 frames against the oracle; coordinates include out-of-map windows (zero padding)."""
+    gen = torch.Generator().manual_seed(5)
+    S, N, C, Hm, r, L = 12, 1024, 128, 128, 4, 4
+    fm = torch.randn(1, S, C, Hm, Hm, generator=gen)
+    tg = torch.randn(1, S, N, C, generator=gen)
+    cd = torch.rand(1, S, N, 2, generator=gen) * (Hm + 12) - 6
+    pyr = O.window_corr_pyramid(fm, L)
+    out = _window_corr_all_levels(hip, [f[0] for f in pyr], tg[0], cd[0], r)
+    sample = torch.randperm(N, generator=gen)[:64]
+    ref = O.window_corr_sample(pyr, tg[:, :, sample], cd[:, :, sample], r)[0]
+    err = (out[:, sample].cpu() - ref).abs().max().item()
+    assert err < 5e-5, err
+
+
+def test_bf16_store_keeps_nan(hip):
+    """A NaN must survive the bf16 activation stores so that the deferred NaN guard sees it (ADVICE / VERDICT weak #6):
+    a bf16-output GEMM with a NaN and an Inf in its input rows."""
+    M, N, K = 64, 64, 64
+    A = torch.randn(M, K)
+    A[3, 5] = float("nan")
+    A[7, 1] = float("inf")
+    Wm = torch.randn(N, K) / 8
+    hi, _ = split(hip, G(pad_w(Wm)), lo=False)
+    out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16(G(A), K, hi, None, hi.shape[1], G(torch.zeros(N)), None, 0, out, N, M, N, K, 0)
+    torch.cuda.synchronize()
+    o = out.float().cpu()
+    assert bool(torch.isnan(o[3]).all()) and bool(torch.isnan(o[7]).any() | torch.isinf(o[7]).any())
+    ok = torch.ones(M, dtype=torch.bool)
+    ok[3] = ok[7] = False
+    assert bool(torch.isfinite(o[ok]).all())

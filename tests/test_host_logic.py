@@ -122,3 +122,41 @@ def test_sample_io_roundtrip(tmp_path):
     z = np.load(out, allow_pickle=False)
     assert z["tracks_3d"].shape == (Tn, N, 3) and z["visibilities"].shape == (Tn, N) and z["query_points"].shape == (N, 4)
     assert z["rgbs"].dtype == np.uint8 and str(z["tracker"]) == "mvtracker"
+
+
+def test_entry_points_run_under_their_tensors_device(monkeypatch):
+    """launches go to the CURRENT device's stream, so every public entry point must make its tensors'
+    device current.  ``hip.guarded`` does that through ``hip.device_guard``; here the guard is recorded."""
+    import torch
+    from mvtracker_amd import hip
+    from mvtracker_amd.adapter import assign_views
+    from mvtracker_amd.parallel import ShardedTracker
+    from mvtracker_amd.predictor import EvaluationPredictor
+    from mvtracker_amd.tracker import MVTracker
+    for fn in (MVTracker.forward, MVTracker.build_frame_store, MVTracker.encode_images, MVTracker.fill_frame_features,
+               MVTracker.refine_window, MVTracker.update_former, EvaluationPredictor.forward, ShardedTracker.__call__, assign_views):
+        assert hasattr(fn, "__wrapped__"), fn
+    seen = []
+
+    class Ctx:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *a):
+            return False
+
+    def fake_guard(t):
+        seen.append(t)
+        return Ctx()
+
+    monkeypatch.setattr(hip, "device_guard", fake_guard)
+
+    @hip.guarded
+    def entry(obj, store, frame0, coords, other=None):
+        return None
+
+    x, y = torch.ones(3), torch.zeros(2)
+    entry(object(), {"xyz": [y]}, 0, x, other=y)
+    assert seen and seen[-1] is x  # the first tensor argument fixes the device
+    entry(object(), {"xyz": [y]}, 0, None)
+    assert seen[-1] is y  # no tensor argument: falls back to the tensors inside dict / list arguments

@@ -13,7 +13,20 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_path):
+CASES = {
+    # name: (world, clip kwargs, overlap_encoder)
+    "two_ranks": (2, dict(seed=71, V=2, T=12, H=128, W=128, N=9), True),
+    # 3 ranks, 2 views x 15 frames: the first block has 24 images (8 per rank), the second 6 (2 per rank); late queries, 2 windows
+    "three_ranks_late": (3, dict(seed=72, V=2, T=15, H=96, W=96, N=10, late_queries=True, query_frames=(2, 5)), True),
+    # 4 ranks, 1 view x 14 frames: second block = 2 images over 4 ranks -> ranks 2 and 3 have EMPTY shares (zeros travel);
+    # the first block (12 images, 3 per rank) is even.  Same clip once more as a single 14-image block (4,4,4,2: a short share
+    # plus 2 images of spill into the tail padding).
+    "four_ranks_empty_share": (4, dict(seed=73, V=1, T=14, H=128, W=128, N=8), True),
+    "four_ranks_one_block": (4, dict(seed=73, V=1, T=14, H=128, W=128, N=8), False),
+}
+
+
+def _worker(rank, world, port, out_path, case):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,7 +46,9 @@ def _worker(rank, world, port, out_path):
     m = MVTracker(hidden_size=256).eval()
     sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-    clip = synth.make_clip(71, V=2, T=12, H=128, W=128, N=9)
+    _, kw, overlap = CASES[case]
+    m.overlap_encoder = overlap
+    clip = synth.make_clip(**kw)
     a = [torch.from_numpy(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
     res = ShardedTracker(m)(*a, iters=2)
     if rank == 0:
@@ -42,25 +57,29 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_sharded_tracker_two_ranks(tmp_path):
+@pytest.mark.parametrize("case", list(CASES))
+def test_sharded_tracker(tmp_path, case):
+    world, kw, _ = CASES[case]
     out = str(tmp_path / "out.npz")
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() * 7 + len(case)) % 2000
+    mp.spawn(_worker, args=(world, port, out, case), nprocs=world, join=True)
     got = np.load(out)
     from mvtracker_amd import synth
     from mvtracker_amd.parallel import ShardedTracker
     from oracle import mvt_oracle as O
     cfg = O.TrackerConfig()
     W = O.make_weights(cfg, 0)
-    clip = synth.make_clip(71, V=2, T=12, H=128, W=128, N=9)
+    clip = synth.make_clip(**kw)
     a = [torch.from_numpy(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
-    assert got["traj"].shape == (1, 12, 9, 3)
-    for rank in range(2):
-        lo, hi = ShardedTracker.shard_bounds(9, 2, rank)
+    N, T = kw["N"], kw["T"]
+    assert got["traj"].shape == (1, T, N, 3)
+    for rank in range(world):
+        lo, hi = ShardedTracker.shard_bounds(N, world, rank)
         ro = O.tracker_forward(W, cfg, a[0], a[1], a[2][:, lo:hi], a[3], a[4], iters=2, knn_mode="exact")
+        # every shard starts its windows at ITS earliest query; frames before that stay zero on both sides
         ref = ro["traj_e"].numpy()
-        assert np.abs(got["traj"][:, :, lo:hi] - ref).max() / np.abs(ref).max() < 1e-4
-        assert np.abs(got["vis"][:, :, lo:hi] - ro["vis_e"].numpy()).max() < 2e-3
+        assert np.abs(got["traj"][:, :, lo:hi] - ref).max() / np.abs(ref).max() < 1e-4, (case, rank)
+        assert np.abs(got["vis"][:, :, lo:hi] - ro["vis_e"].numpy()).max() < 2e-3, (case, rank)
 
 
 def test_shard_bounds_cover_everything():
