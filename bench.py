@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
 """Headline benchmark: query-points x frames / second of the multi-view tracking forward path.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 10 --warmup 2 [--config c3|c2|c5shard]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one full tracker call (encode 4 views x 24 frames of 512x512, build the frame store,
-3 sliding windows x 4 refinement iterations, 1024 queries) on synthetic inputs already resident in HBM
-(BASELINE.json config "4-view 24-frame 512x512 @1024 queries"; one corr_gather_dot launch covers the 4 pyramid
-levels of one refinement iteration = 4 x 12288 units x 9164 B = 450 MB of algorithmic traffic).  With N > 1 every rank tracks its own
-1024-query shard (weak scaling; shard = independent forward) and the frames are
-encoded once across the node: rank r encodes frames r, r+N, ... and the level-0 feature maps are
-all-gathered over RCCL/xGMI before the refinement loop, which contains no collective.
+One "step" = one full tracker call on synthetic inputs already resident in HBM: encode the V x T frames, build the frame store,
+sliding windows x 4 refinement iterations.  Default workload = BASELINE.json's headline config C3 (4 views x 24 frames x 512x512,
+1024 queries, bf16): 3 windows; one corr_gather_dot launch covers the 4 pyramid levels of one refinement iteration = 4 x 12288
+units x 4812 B (bf16 feature rows; 9164 B with the fp32 rows of the fp32 / bf16x3 modes) of algorithmic traffic.
+With N > 1 every rank tracks its own 1024-query shard (weak scaling; shard = independent forward) and the
+frames are encoded once across the node: the V x T images are cut evenly across the ranks (contiguous runs of the frame-major
+image list), each rank encodes its run into its slot of the level-0 store and the slots are all-gathered in place over
+RCCL/xGMI before the refinement loop, which contains no collective.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live for the HBM-bound gather-dot correlation
-kernel with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the
+Prints ONE JSON line (rank 0).  `roofline` is measured live for the HBM-bound gather-dot correlation kernel with HIP events on
+the launch stream; `roofline_mfma` gives the matrix-core fraction of the two MFMA-bound stages (updater transformer, CNN
+encoder; flops recomputed from the shapes, HIP events around every call); `cpu_baseline` times the CPU oracle (a port of the
 reference's algorithm, its CPU fallback kNN) on a bounded sample of the same workload on this host.
 """
 import argparse
@@ -29,16 +31,58 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak; fp32 MFMA 157.3
+MFMA_F32_TFLOPS = 157.3
+
+CONFIGS = {
+    # name: (views, frames, H, W, queries per GPU, precision, extra make_clip kwargs, BASELINE.json config it is)
+    "c3": (4, 24, 512, 512, 1024, "bf16", {}, "4-view synthetic 24-frame 512x512, 1024 queries, bf16 (configs[2], the metric's config)"),
+    "c2": (3, 24, 384, 512, 512, "fp32", {"invalid_frac": 0.02}, "3-view 24 frames 384x512, 512 query points, fp32 (configs[1])"),
+    "c5shard": (6, 64, 720, 1280, 512, "bf16", {"frame_period": 4, "rgb_dtype": np.uint8},
+                "one GPU's 512-query shard of the 6-view 64-frame 720p config (configs[4])"),
+}
 
 
-def corr_algorithmic_bytes(rows, K=16, C=128):
-    """per (frame, track, level) K rows x C x 4 B gathered + K x 12 B neighbour xyz
-    + C x 4 B target + 12 B coord read, K x 16 B written = 9164 B at K=16, C=128 (fp32)."""
-    return rows * (K * C * 4 + K * 12 + C * 4 + 12 + K * 16)
+def corr_algorithmic_bytes(rows, K=16, C=128, elem=4):
+    """per (frame, track, level) K rows x C x e_f gathered + K x 12 B neighbour xyz + C x e_f target
+    + 12 B coord read, K x 16 B written = 9164 B (fp32 rows) / 4812 B (bf16 rows) at K=16, C=128."""
+    return rows * (K * C * elem + K * 12 + C * elem + 12 + K * 16)
 
 
-def cpu_baseline(args):
+def updater_flops(n, S=12, h=256, inner=288, mlp=1024, D=581, out=131, nv=64, heads=6, dh=48, depth=6):
+    """EfficientUpdateFormer.forward on n tracks (cotracker2/blocks.py:455-494), multiply-adds x 2, from the shapes."""
+    Mp, Mv = n * S, nv * S
+    M = Mp + Mv
+    lin = lambda rows, k, nn: 2.0 * rows * k * nn
+    att = lambda groups, nq, nk: 4.0 * groups * heads * nq * nk * dh
+    blk = lambda rows: lin(rows, inner, h) + lin(rows, h, mlp) + lin(rows, mlp, h)
+    f = lin(Mp, D, h)
+    per = (lin(M, h, 3 * inner) + att(n + nv, S, S) + blk(M)                     # time block
+           + lin(Mv, h, inner) + lin(Mp, h, 2 * inner) + att(S, nv, n) + blk(Mv)   # virtual <- point
+           + lin(Mv, h, 3 * inner) + att(S, nv, nv) + blk(Mv)                      # virtual self
+           + lin(Mp, h, inner) + lin(Mv, h, 2 * inner) + att(S, n, nv) + blk(Mp))  # point <- virtual
+    f += depth * per
+    f += lin(Mp, h, out) + 2 * lin(Mp, out, out)
+    return f
+
+
+def encoder_flops(H, W, C=128):
+    """BasicEncoder.forward on one H x W image (spatracker/blocks.py:214-284), multiply-adds x 2."""
+    conv = lambda ho, wo, cout, cin, k: 2.0 * ho * wo * cout * cin * k * k
+    h2, w2 = H // 2, W // 2
+    f = conv(h2, w2, 64, 3, 7)
+    f += 4 * conv(h2, w2, 64, 64, 3)
+    cin, h, w = 64, h2, w2
+    for cout in (96, 128, 128):
+        h, w = h // 2, w // 2
+        f += conv(h, w, cout, cin, 3) + 3 * conv(h, w, cout, cout, 3) + conv(h, w, cout, cin, 1)
+        cin = cout
+    f += conv(H // 4, W // 4, 2 * C, 416, 3) + conv(H // 4, W // 4, C, 2 * C, 1)
+    return f
+
+
+def cpu_baseline(args, V, HW):
     """Oracle (port of the reference algorithm, CPU fallback kNN = cdist+topk) on a bounded sample."""
     from mvtracker_amd import synth
     from oracle import mvt_oracle as O
@@ -48,7 +92,12 @@ def cpu_baseline(args):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, args.cpu_threads))  # the GPU box gives one GPU a 16-core CPU share
     torch.set_num_threads(cores)
-    V, T, H, W, N = 4, 12, args.cpu_hw, args.cpu_hw, 256  # the workload's views / image size, one window, a quarter of the queries
+    H, W = HW
+    if args.cpu_hw:
+        H = W = args.cpu_hw
+    elif H * W > 512 * 512:  # (720p clips: a quarter-resolution sample keeps the CPU leg within ~30 s)
+        H, W = H // 2, W // 2
+    T, N = 12, 256  # the workload's views / image size, one window, a quarter of the queries
     clip = synth.make_clip(1234, V=V, T=T, H=H, W=W, N=N)
     cfg = O.TrackerConfig()
     Wt = O.make_weights(cfg, 0)
@@ -58,6 +107,8 @@ def cpu_baseline(args):
         O.tracker_forward(Wt, cfg, *a, iters=4, knn_mode="cdist")
     dt = time.time() - t0
     return {"value": N * T / dt, "unit": "query-points*frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            # a quarter-size sample (12 of 24 frames, 256 of 1024 queries: ~10 s instead of ~65 s) keeps the default run short;
+            # the kNN cost per query-frame is the same, the encoder cost per query-frame is 2x the full clip's
             "sample": f"oracle.tracker_forward, {V} views x {T} frames x {H}x{W}, {N} queries, 1 window x 4 iters, fp32, "
                       f"{dt:.1f} s wall"}
 
@@ -65,17 +116,18 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--views", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=24)
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--queries", type=int, default=1024, help="queries per GPU")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="BASELINE.json workload (default: the metric's config C3)")
+    ap.add_argument("--views", type=int)
+    ap.add_argument("--frames", type=int)
+    ap.add_argument("--size", type=int)
+    ap.add_argument("--queries", type=int, help="queries per GPU")
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="bf16",
-                    help="matrix-core arithmetic of convs/linears; BASELINE.json quotes this config in bf16")
-    ap.add_argument("--cpu-hw", type=int, default=512)
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"],
+                    help="matrix-core arithmetic of convs/linears (default: the config's dtype; BASELINE.json quotes C3 in bf16)")
+    ap.add_argument("--cpu-hw", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
@@ -95,32 +147,42 @@ def main():
     from mvtracker_amd.parallel import ShardedTracker
     from mvtracker_amd.tracker import MVTracker
 
+    V, T, H, W, Nq, prec, clip_kw, what = CONFIGS[args.config]
+    V, T, Nq = args.views or V, args.frames or T, args.queries or Nq
+    if args.size:
+        H = W = args.size
+    prec = args.precision or prec
+
     model = MVTracker(hidden_size=256).eval()
     sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.to(dev)
-    if args.precision:
-        model.precision = args.precision
-    V, T, HW, Nq = args.views, args.frames, args.size, args.queries
-    clip = synth.make_clip(1234, V=V, T=T, H=HW, W=HW, N=Nq * world)  # same clip on every rank
+    model.precision = prec
+    clip = synth.make_clip(1234, V=V, T=T, H=H, W=W, N=Nq * world, **clip_kw)  # same clip on every rank
     a = {k: torch.from_numpy(v).to(dev) for k, v in clip.items()}
     runner = ShardedTracker(model)
 
-    # live per-launch timing of the correlation kernel (HIP events on the launch stream)
-    events = []
-    real_corr = hip.corr_gather_dot
+    # live timing with HIP events on the launch stream (torch events record on the current stream, which is the launch stream):
+    # every launch of the correlation kernel, every updater call, every encoder chunk
+    corr_ev, upd_ev, enc_ev = [], [], []
     timing = {"on": False}
+    real_corr, real_upd, real_enc = hip.corr_gather_dot, model._update_former, model._encode
 
-    def timed_corr(*cargs, **ckw):
-        if not timing["on"]:
-            return real_corr(*cargs, **ckw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        real_corr(*cargs, **ckw)
-        e1.record()
-        events.append((e0, e1, cargs[7] * cargs[8]))  # rows = N * S
+    def timed(real, sink, tag):
+        def f(*cargs, **ckw):
+            if not timing["on"]:
+                return real(*cargs, **ckw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = real(*cargs, **ckw)
+            e1.record()
+            sink.append((e0, e1, tag(*cargs, **ckw)))
+            return r
+        return f
 
-    hip.corr_gather_dot = timed_corr
+    hip.corr_gather_dot = timed(real_corr, corr_ev, lambda *c, **k: c[7] * c[8])          # rows = N * S
+    model._update_former = timed(real_upd, upd_ev, lambda pk, x, ldx, n, *r, **k: n)       # tracks of the call
+    model._encode = timed(real_enc, enc_ev, lambda pk, x4, n, *r, **k: n)                  # images of the chunk
 
     def step():
         return runner(a["rgbs"], a["depths"], a["query_points"], a["intrs"], a["extrs"], iters=args.iters, gather_output=False)
@@ -135,9 +197,12 @@ def main():
         step()
     barrier()
     timing["on"] = True
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()  # (no sync between steps: the K steps are timed as one bracketed region)
     barrier()
     dt = time.perf_counter() - t0
     timing["on"] = False
@@ -151,36 +216,60 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * Nq * T / (dt / args.steps)
-        full = [(e0.elapsed_time(e1), rows) for e0, e1, rows in events if rows == Nq * model.S]
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        store_bf16 = model.store_dtype() == torch.bfloat16
+        full = [(e0.elapsed_time(e1), rows) for e0, e1, rows in corr_ev if rows == Nq * model.S]
         kern_ms = float(np.mean([m for m, _ in full])) if full else float("nan")
-        alg = model.corr_n_levels * corr_algorithmic_bytes(Nq * model.S, model.corr_neighbors, model.latent_dim)
+        alg = model.corr_n_levels * corr_algorithmic_bytes(Nq * model.S, model.corr_neighbors, model.latent_dim, 2 if store_bf16 else 4)
         achieved = alg / (kern_ms * 1e-3) / 1e9 if full else float("nan")
         # HBM traffic of the roofline kernel: PMC measurement committed under profiles/ (tools/pmc_traffic.sh; counters cannot
         # be collected from inside the timed run).  Only quoted for the workload it was measured on.
         traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_corr_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("algorithmic_bytes_per_launch") == alg:
-                traffic = tj["traffic_bytes_per_launch"]
+        for name in ("r02_corr_traffic.json", "r01_corr_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("algorithmic_bytes_per_launch") == alg:
+                    traffic = tj["traffic_bytes_per_launch"]
+                    break
+        peak_tf = MFMA_F32_TFLOPS if prec == "fp32" else MFMA_BF16_TFLOPS
+        upd_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in upd_ev) / args.steps
+        upd_fl = sum(updater_flops(n, model.S) for _, _, n in upd_ev) / args.steps
+        enc_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in enc_ev) / args.steps
+        enc_fl = sum(n * encoder_flops(H, W, model.latent_dim) for _, _, n in enc_ev) / args.steps
+        x3 = 3.0 if prec == "bf16x3" else 1.0  # three bf16 MFMAs per product in the split-precision mode
+
+        def mfma(fl, t_ms, calls):
+            tf = fl / (t_ms * 1e-3) / 1e12 if t_ms > 0 else float("nan")
+            return {"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf * x3 / peak_tf,
+                    "flops_per_step": fl, "ms_per_step": t_ms, "calls_per_step": calls}
+
         out = {
             "metric": "query-points*frames/sec, 4-view 24-frame 512x512 @1024 queries",
             "value": value, "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-precision bf16 MFMA, f32 accumulate, f32-grade)", "bf16": "bf16"}[model.precision],
+            "ms_per_step": ms, "ms_per_step_median": float(np.median(per_step)), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-precision bf16 MFMA, f32 accumulate, f32-grade)", "bf16": "bf16"}[prec],
             "data": "synthetic",
-            "config": {"workload": f"{V}-view {T}-frame {HW}x{HW}, {Nq} queries per GPU, corr K=16 x 4 levels, iters={args.iters}, "
-                                   f"3 windows, random-init weights (seeded recipe)",
-                       "queries_total": Nq * world, "parallelism": f"query-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "corr_gather_dot_kernel<32>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "config": {"workload": f"{args.config}: {what}; {V}-view {T}-frame {H}x{W}, {Nq} queries per GPU, corr K=16 x 4 levels, "
+                                   f"iters={args.iters}, {len(model.last_windows)} windows, random-init weights (seeded recipe)",
+                       "queries_total": Nq * world, "parallelism": f"query-shard x{world}",
+                       "frame_store": "bf16 rows" if store_bf16 else "fp32 rows"},
+            "roofline": {"bound": "hbm", "kernel": "corr_gather_dot_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms, "launches_timed": len(full),
+                         # `achieved` prices the ALGORITHMIC bytes; the same launch time over the HBM bytes the
+                         # PMC counters saw (neighbouring tracks share rows in L2) is the physical HBM rate
+                         "hbm_GBps_from_traffic": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and full) else None,
+                         "algorithmic_bytes_per_launch": alg, "bytes_per_unit": alg // (model.corr_n_levels * Nq * model.S),
+                         "avg_launch_ms": kern_ms, "launches_timed": len(full),
                          # launches of the last window run alone; earlier ones share HBM with the encoder of the later
                          # frames on the second stream (the average above includes that contention)
                          "min_launch_ms": float(np.min([m for m, _ in full])) if full else None},
+            "roofline_mfma": {"updater": mfma(upd_fl, upd_ms, len(upd_ev) // args.steps),
+                              "encoder": mfma(enc_fl, enc_ms, len(enc_ev) // args.steps)},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, V, (H, W))
         print(json.dumps(out), flush=True)
     if world > 1 or os.environ.get("MVT_FORCE_SHARDED"):
         import torch.distributed as dist

@@ -210,8 +210,10 @@ int mvt_depth_subsample(const float* depths, float* out, int V, int T, int H, in
  * xyz_out NULL or [V][N][3] = (pixel x, pixel y, camera z) of every query in every view. */
 int mvt_adapter_best_view(const float* depths, const float* intrs, const float* extrs, const float* query_points, int V, int T,
                           int H, int W, int N, int* view_out, float* xyz_out, void* stream);
-/* 2x2 average pool of channels-last [n][h][w][C] -> [n][h/2][w/2][C] (model_utils.py:440). */
-int mvt_avgpool2(const float* in, float* out, long long n, int h, int w, int C, void* stream);
+/* 2x2 average pool of channels-last [n][h][w][C] -> [n][h/2][w/2][C] (model_utils.py:440).  io_flags: 0 (fp32 rows) or
+ * MVT_IO_IN_BF16 | MVT_IO_OUT_BF16 (the bf16 frame store of bf16 mode -- under autocast the reference's fmaps are bf16 and
+ * every pooled level is rounded to bf16 again, model_utils.py:436-440; the 2x2 mean itself is taken in fp32). */
+int mvt_avgpool2(const void* in, void* out, long long n, int h, int w, int C, int io_flags, void* stream);
 /* xyz_l [T][V][h_l][w_l][4] from level-0 strided depth [T][V][hs][ws] (nearest-subsampled by
  * 2^level, model_utils.py:443-444), pixel grid (i+0.5)*stride*2^level-0.5 (:462-466), kinv/einv
  * indexed [v*T+t] (:467-473). */
@@ -269,13 +271,14 @@ int mvt_knn_merge_levels(int levels, const mvt_knn_level* lv, int N, int S, int 
  * DEVICE pointers: xyz[l] [T][P_l][4], fvec[l] [T][P_l][C] (C in {32,64,128,256}, groups == 1), idx[l]
  * [N][S][K] int32 from mvt_knn_merge, P[l].  For k < K:
  *   out[(n*S+s)*ldo + o_off + l*4K + 4k + {0,1,2,3}] = { <target, f_k>/sqrt(C), xyz_k - coord }
- * (mvtracker.py:827-842 with corr_add_neighbor_offset=True; the level-major concat of :374).  targets [N][S][C]. */
-int mvt_corr_gather_dot(int levels, const float* const* xyz, const float* const* fvec, const long long* P,
+ * (mvtracker.py:827-842 with corr_add_neighbor_offset=True; the level-major concat of :374).  targets [N][S][C] fp32.
+ * fvec_bf16: the feature rows are bf16 (256-B rows at C = 128; the dot accumulates in fp32).  ldo, o_off multiples of 4. */
+int mvt_corr_gather_dot(int levels, const float* const* xyz, const void* const* fvec, int fvec_bf16, const long long* P,
                         const int* const* idx, int C, const float* targets, const float* coords, int N, int S,
                         int frame0, int frame_step, int T, int K, float* out, int ldo, int o_off, void* stream);
-/* 1-NN feature init: feat_out[n][C] = fvec[frame][idx] with idx from keys [n][1][nseg][1]
- * (mvtracker.py:640-643); idx_out optional. */
-int mvt_knn1_gather(const float* fvec, long long P, int C, const unsigned long long* keys, int n, int nseg,
+/* 1-NN feature init: feat_out[n][C] (fp32) = fvec[frame][idx] with idx from keys [n][1][nseg][1]
+ * (mvtracker.py:640-643); idx_out optional.  fvec_bf16: bf16 feature rows. */
+int mvt_knn1_gather(const void* fvec, int fvec_bf16, long long P, int C, const unsigned long long* keys, int n, int nseg,
                     int frame, float* feat_out, int* idx_out, void* stream);
 
 /* Secondary operator: bilinear-window correlation (CorrBlock.corr_sample,

@@ -405,11 +405,15 @@ struct CorrLevels {
   long long P[8];
 };
 
-template <int LPR>  // lanes per feature row: C = 4 * LPR
+// One wave per (track, frame) unit and level: gather the K neighbour rows, dot with the target, neighbour offsets.
+// LPR lanes cover one feature row with 16 bytes each: C = 4 * LPR fp32 values, or (BF) C = 8 * LPR bf16 values -- the bf16
+// frame store of bf16 mode, 256-B rows at C = 128: four rows per 1-KiB wave load, fp32 dot accumulation.
+template <int LPR, int BF>
 __global__ __launch_bounds__(256) void corr_gather_dot_kernel(CorrLevels lv, const float* __restrict__ targets,
                                                               const float* __restrict__ coords, int N, int S, int frame0,
                                                               int frame_step, int T, int K, float* __restrict__ out, int ldo, int o_off) {
-  constexpr int C = 4 * LPR;
+  constexpr int EPL = BF ? 8 : 4;  // elements per lane
+  constexpr int C = EPL * LPR;
   constexpr int RPL = 64 / LPR;  // rows per wave load
   const int lane = threadIdx.x & 63;
   const int level = blockIdx.y;
@@ -426,15 +430,25 @@ __global__ __launch_bounds__(256) void corr_gather_dot_kernel(CorrLevels lv, con
   if ((long long)idx >= P) idx = (unsigned)(P - 1);
 
   const int sub = lane / LPR, cq = lane % LPR;
-  const f32x4 tg = *reinterpret_cast<const f32x4*>(targets + row * C + cq * 4);
-  const float* fbase = fvec + (long long)frame * P * C + cq * 4;
-  constexpr int MAXJ = 16 / RPL;
-  f32x4 f[MAXJ];
+  f32x4 tg[EPL / 4];
+#pragma unroll
+  for (int e = 0; e < EPL / 4; ++e) tg[e] = *reinterpret_cast<const f32x4*>(targets + row * C + cq * EPL + 4 * e);
+  const long long fbase = (long long)frame * P * C + cq * EPL;  // element offset into the level's rows
+  constexpr int MAXJ = (16 + RPL - 1) / RPL;
+  f32x4 f[MAXJ][EPL / 4];
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     const int k = j * RPL + sub;
     const unsigned ik = __shfl(idx, k < K ? k : 0, 64);
-    f[j] = *reinterpret_cast<const f32x4*>(fbase + (long long)ik * C);
+    if (BF) {
+      const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(fvec) + fbase + (long long)ik * C);
+      f[j][0] = (f32x4){__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16),
+                        __uint_as_float(w.y & 0xFFFF0000u)};
+      f[j][EPL / 4 - 1] = (f32x4){__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xFFFF0000u), __uint_as_float(w.w << 16),
+                                  __uint_as_float(w.w & 0xFFFF0000u)};
+    } else {
+      f[j][0] = *reinterpret_cast<const f32x4*>(fvec + fbase + (long long)ik * C);
+    }
   }
   // neighbour offsets (lane k < K)
   const f32x4 nx = *reinterpret_cast<const f32x4*>(xyz + ((long long)frame * P + idx) * 4);
@@ -445,10 +459,14 @@ __global__ __launch_bounds__(256) void corr_gather_dot_kernel(CorrLevels lv, con
   float mine = 0.f;
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
-    float d = tg[0] * f[j][0];
-    d = fmaf(tg[1], f[j][1], d);
-    d = fmaf(tg[2], f[j][2], d);
-    d = fmaf(tg[3], f[j][3], d);
+    float d = tg[0][0] * f[j][0][0];
+    d = fmaf(tg[0][1], f[j][0][1], d);
+    d = fmaf(tg[0][2], f[j][0][2], d);
+    d = fmaf(tg[0][3], f[j][0][3], d);
+    if (BF) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d = fmaf(tg[EPL / 4 - 1][e], f[j][EPL / 4 - 1][e], d);
+    }
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
     // lane k takes the value of its (j, sub) = (k / RPL, k % RPL)
@@ -457,13 +475,11 @@ __global__ __launch_bounds__(256) void corr_gather_dot_kernel(CorrLevels lv, con
   }
   if (lane < K) {
     float* o = out + row * ldo + o_off + level * K * 4 + lane * 4;
-    o[0] = mine / scale;
-    o[1] = ox;
-    o[2] = oy;
-    o[3] = oz;
+    *reinterpret_cast<f32x4*>(o) = (f32x4){mine / scale, ox, oy, oz};
   }
 }
 
+template <int BF>
 __global__ __launch_bounds__(256) void knn1_gather_kernel(const float* __restrict__ fvec, long long P, int C,
                                                           const unsigned long long* __restrict__ keys, int n, int nseg, int frame,
                                                           float* __restrict__ feat_out, int* __restrict__ idx_out) {
@@ -475,9 +491,8 @@ __global__ __launch_bounds__(256) void knn1_gather_kernel(const float* __restric
   unsigned idx = (unsigned)key;
   if ((long long)idx >= P) idx = (unsigned)(P - 1);
   if (idx_out && lane == 0) idx_out[q] = (int)idx;
-  const float* src = fvec + ((long long)frame * P + idx) * C;
-  for (int c = lane * 4; c < C; c += 256)
-    *reinterpret_cast<f32x4*>(feat_out + (long long)q * C + c) = *reinterpret_cast<const f32x4*>(src + c);
+  const long long src = ((long long)frame * P + idx) * C;
+  for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(feat_out + (long long)q * C + c) = load_act4(fvec, src + c, BF);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -638,40 +653,56 @@ extern "C" int mvt_knn_merge(const unsigned long long* keys, int N, int S, int K
   return mvt_launch_status();
 }
 
-extern "C" int mvt_corr_gather_dot(int levels, const float* const* xyz, const float* const* fvec, const long long* P,
+extern "C" int mvt_corr_gather_dot(int levels, const float* const* xyz, const void* const* fvec, int fvec_bf16, const long long* P,
                                    const int* const* idx, int C, const float* targets, const float* coords, int N, int S,
                                    int frame0, int frame_step, int T, int K, float* out, int ldo, int o_off, void* stream) {
   MVT_REQUIRE(levels >= 1 && levels <= 8 && xyz && fvec && P && idx && targets && coords && out);
+  MVT_REQUIRE((fvec_bf16 == 0 || fvec_bf16 == 1) && ldo % 4 == 0 && o_off % 4 == 0 && ((uintptr_t)out % 16 == 0));
   MVT_REQUIRE(N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0 && K >= 1 && K <= 16);
   MVT_REQUIRE(o_off >= 0 && ldo >= o_off + levels * 4 * K);
   CorrLevels lv{};
   for (int l = 0; l < levels; ++l) {
     MVT_REQUIRE(xyz[l] && fvec[l] && idx[l] && P[l] >= K && P[l] < (1LL << 31));
     lv.xyz[l] = xyz[l];
-    lv.fvec[l] = fvec[l];
+    lv.fvec[l] = (const float*)fvec[l];
     lv.idx[l] = idx[l];
     lv.P[l] = P[l];
   }
   const dim3 grid((unsigned)mvt_cdiv((long long)N * S, 4), (unsigned)levels);
-#define LAUNCH(LPR)                                                                                                              \
-  hipLaunchKernelGGL((corr_gather_dot_kernel<LPR>), grid, dim3(256), 0, mvt_stream(stream), lv, targets, coords, N, S, frame0, frame_step, \
-                     T, K, out, ldo, o_off)
-  switch (C) {
-    case 32: LAUNCH(8); break;
-    case 64: LAUNCH(16); break;
-    case 128: LAUNCH(32); break;
-    case 256: LAUNCH(64); break;
-    default: return MVT_ERR_ARG;
+#define LAUNCH(LPR, BF)                                                                                                              \
+  hipLaunchKernelGGL((corr_gather_dot_kernel<LPR, BF>), grid, dim3(256), 0, mvt_stream(stream), lv, (const float*)targets, coords, N, S, \
+                     frame0, frame_step, T, K, out, ldo, o_off)
+  if (fvec_bf16) {
+    switch (C) {
+      case 32: LAUNCH(4, 1); break;
+      case 64: LAUNCH(8, 1); break;
+      case 128: LAUNCH(16, 1); break;
+      case 256: LAUNCH(32, 1); break;
+      default: return MVT_ERR_ARG;
+    }
+  } else {
+    switch (C) {
+      case 32: LAUNCH(8, 0); break;
+      case 64: LAUNCH(16, 0); break;
+      case 128: LAUNCH(32, 0); break;
+      case 256: LAUNCH(64, 0); break;
+      default: return MVT_ERR_ARG;
+    }
   }
 #undef LAUNCH
   return mvt_launch_status();
 }
 
-extern "C" int mvt_knn1_gather(const float* fvec, long long P, int C, const unsigned long long* keys, int n, int nseg, int frame,
-                               float* feat_out, int* idx_out, void* stream) {
+extern "C" int mvt_knn1_gather(const void* fvec, int fvec_bf16, long long P, int C, const unsigned long long* keys, int n, int nseg,
+                               int frame, float* feat_out, int* idx_out, void* stream) {
   MVT_REQUIRE(fvec && keys && feat_out && n > 0 && nseg >= 1 && nseg <= 64 && C > 0 && C % 4 == 0 && P > 0 && frame >= 0);
-  hipLaunchKernelGGL(knn1_gather_kernel, dim3((unsigned)mvt_cdiv(n, 4)), dim3(256), 0, mvt_stream(stream), fvec, P, C, keys, n, nseg,
-                     frame, feat_out, idx_out);
+  MVT_REQUIRE(fvec_bf16 == 0 || fvec_bf16 == 1);
+  if (fvec_bf16)
+    hipLaunchKernelGGL(knn1_gather_kernel<1>, dim3((unsigned)mvt_cdiv(n, 4)), dim3(256), 0, mvt_stream(stream), (const float*)fvec, P, C, keys,
+                       n, nseg, frame, feat_out, idx_out);
+  else
+    hipLaunchKernelGGL(knn1_gather_kernel<0>, dim3((unsigned)mvt_cdiv(n, 4)), dim3(256), 0, mvt_stream(stream), (const float*)fvec, P, C, keys,
+                       n, nseg, frame, feat_out, idx_out);
   return mvt_launch_status();
 }
 

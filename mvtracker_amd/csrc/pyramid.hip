@@ -48,8 +48,10 @@ __global__ void depth_subsample_kernel(const float* __restrict__ d, float* __res
   }
 }
 
+template <int BF>  // BF: bf16 rows in and out (the bf16 frame store); the 2x2 mean is taken in fp32 either way
 __global__ void avgpool2_kernel(const float* __restrict__ in, float* __restrict__ out, long long n, int h, int w, int C) {
-  const int ho = h / 2, wo = w / 2, cq = C / 4;
+  constexpr int E = BF ? 8 : 4;  // elements per 16-byte lane access
+  const int ho = h / 2, wo = w / 2, cq = C / E;
   const long long total = n * ho * wo * cq;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     int q = (int)(i % cq);
@@ -58,15 +60,16 @@ __global__ void avgpool2_kernel(const float* __restrict__ in, float* __restrict_
     long long r = pix / wo;
     int y = (int)(r % ho);
     long long img = r / ho;
-    const float* b = in + ((img * h + 2 * y) * (long long)w + 2 * x) * C + q * 4;
-    f32x4 a = *reinterpret_cast<const f32x4*>(b);
-    f32x4 bb = *reinterpret_cast<const f32x4*>(b + C);
-    f32x4 c = *reinterpret_cast<const f32x4*>(b + (long long)w * C);
-    f32x4 d = *reinterpret_cast<const f32x4*>(b + (long long)w * C + C);
-    f32x4 o;
+    const long long b = ((img * h + 2 * y) * (long long)w + 2 * x) * C + q * E;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (((a[e] + bb[e]) + c[e]) + d[e]) * 0.25f;  // torch avg_pool2d accumulation order
-    *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    for (int hf = 0; hf < E / 4; ++hf) {
+      const f32x4 a = load_act4(in, b + 4 * hf, BF), bb = load_act4(in, b + C + 4 * hf, BF);
+      const f32x4 c = load_act4(in, b + (long long)w * C + 4 * hf, BF), d = load_act4(in, b + (long long)w * C + C + 4 * hf, BF);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (((a[e] + bb[e]) + c[e]) + d[e]) * 0.25f;  // torch avg_pool2d accumulation order
+      store_act4(out, i * E + 4 * hf, o, BF);
+    }
   }
 }
 
@@ -166,10 +169,15 @@ extern "C" int mvt_depth_subsample(const float* depths, float* out, int V, int T
   return mvt_launch_status();
 }
 
-extern "C" int mvt_avgpool2(const float* in, float* out, long long n, int h, int w, int C, void* stream) {
-  MVT_REQUIRE(in && out && n > 0 && h >= 2 && w >= 2 && C > 0 && C % 4 == 0);
-  long long total = n * (h / 2) * (w / 2) * (C / 4);
-  hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), in, out, n, h, w, C);
+extern "C" int mvt_avgpool2(const void* in, void* out, long long n, int h, int w, int C, int io_flags, void* stream) {
+  const int bf = io_flags == (MVT_IO_IN_BF16 | MVT_IO_OUT_BF16);
+  MVT_REQUIRE(io_flags == 0 || bf);  // the pyramid keeps the element type of level 0
+  MVT_REQUIRE(in && out && n > 0 && h >= 2 && w >= 2 && C > 0 && C % (bf ? 8 : 4) == 0);
+  long long total = n * (h / 2) * (w / 2) * (C / (bf ? 8 : 4));
+  if (bf)
+    hipLaunchKernelGGL(avgpool2_kernel<1>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), (const float*)in, (float*)out, n, h, w, C);
+  else
+    hipLaunchKernelGGL(avgpool2_kernel<0>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), (const float*)in, (float*)out, n, h, w, C);
   return mvt_launch_status();
 }
 

@@ -49,7 +49,7 @@ SIGNATURES = {
     "mvt_resize_bilinear_ac": [P, P, I, I, I, I, I, I, I, I, I, P],
     "mvt_invert_cameras": [P, P, P, P, I, P],
     "mvt_depth_subsample": [P, P, I, I, I, I, I, P],
-    "mvt_avgpool2": [P, P, LL, I, I, I, P],
+    "mvt_avgpool2": [P, P, LL, I, I, I, I, P],
     "mvt_unproject": [P, P, P, P, I, I, I, I, I, I, P],
     "mvt_tile_aabb": [P, LL, I, I, I, P, P],
     "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P, I, I, P],
@@ -58,8 +58,8 @@ SIGNATURES = {
     "mvt_adapter_best_view": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mvt_knn_scan_levels": [I, P, P, I, I, I, I, I, I, I, P],
     "mvt_knn_merge_levels": [I, P, I, I, I, P],
-    "mvt_corr_gather_dot": [I, P, P, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
-    "mvt_knn1_gather": [P, LL, I, P, I, I, I, P, P, P],
+    "mvt_corr_gather_dot": [I, P, P, I, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
+    "mvt_knn1_gather": [P, I, LL, I, P, I, I, I, P, P, P],
     "mvt_window_corr": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mvt_pos_embed": [P, I, I, I, I, P, P],
     "mvt_token_assemble": [P, P, I, P, I, P, P, P, I, I, I, P, I, P],
@@ -287,7 +287,8 @@ def depth_subsample(depths, out, V, T, H, W, s):
 
 
 def avgpool2(x, out, n, h, w, Cc):
-    _call("mvt_avgpool2", _ptr(x), _ptr(out), n, h, w, Cc, _stream())
+    assert x.dtype == out.dtype
+    _call("mvt_avgpool2", _ptr(x), _ptr(out), n, h, w, Cc, _io(x, out), _stream())
 
 
 def unproject(depth_s, kinv, einv, xyz, V, T, hs, ws, stride, level):
@@ -346,13 +347,16 @@ def corr_gather_dot(xyz_l, fvec_l, P_l, idx_l, Cc, targets, coords, N, S, frame0
     """xyz_l / fvec_l / idx_l: lists of per-level device tensors; P_l: list of point counts."""
     n = len(xyz_l)
     pa = (C.c_void_p * n)
-    _call("mvt_corr_gather_dot", n, pa(*[_ptr(t) for t in xyz_l]), pa(*[_ptr(t) for t in fvec_l]), (C.c_longlong * n)(*P_l),
+    bf = fvec_l[0].dtype == torch.bfloat16
+    assert all((t.dtype == torch.bfloat16) == bf for t in fvec_l)
+    _call("mvt_corr_gather_dot", n, pa(*[_ptr(t) for t in xyz_l]), pa(*[_ptr(t) for t in fvec_l]), 1 if bf else 0, (C.c_longlong * n)(*P_l),
           pa(*[_ptr(t) for t in idx_l]), Cc, _ptr(targets), _ptr(coords), N, S, frame0, frame_step, T, K, _ptr(out), ldo, o_off,
           _stream())
 
 
 def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):
-    _call("mvt_knn1_gather", _ptr(fvec), Pn, Cc, _ptr(keys), n, nseg, frame, _ptr(feat_out), _ptr(idx_out), _stream())
+    _call("mvt_knn1_gather", _ptr(fvec), 1 if fvec.dtype == torch.bfloat16 else 0, Pn, Cc, _ptr(keys), n, nseg, frame, _ptr(feat_out),
+          _ptr(idx_out), _stream())
 
 
 def window_corr(fmap, targets, coords, out, BS, N, Cc, h, w, level, radius, ldo, o_off):

@@ -77,7 +77,7 @@ class ShardedTracker:
             # chunks, so a block whose image count is not a multiple of world spills at most world - 1 images past its end --
             # into the next block's frames (rewritten when that block is exchanged, later on the same or on the ordered side
             # stream) or, for the last block, into the padding.
-            storage = torch.empty(T * V + world - 1, hs, ws, C, device=dev)
+            storage = torch.empty(T * V + world - 1, hs, ws, C, device=dev, dtype=m.store_dtype())
             level0 = storage[:T * V].view(T, V, hs, ws, C)
             level0[:t0].zero_()  # (never read: no window starts before the first query frame)
 

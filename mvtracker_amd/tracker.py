@@ -122,6 +122,7 @@ class MVTracker(nn.Module):
         self._scratch = {}
         self.bf16_tokens = os.environ.get("MVT_BF16_TOK", "1") != "0"  # bf16 mode: q/k/v and attention outputs stored as bf16
         self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
+        self.bf16_store = os.environ.get("MVT_BF16_STORE", "1") != "0"  # bf16 mode: bf16 feature rows in the frame store
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
         d = self.updateformer_input_dim
@@ -305,6 +306,12 @@ class MVTracker(nn.Module):
             st = self._inorm(out, n, Ho * Wo, cout, apply=False)
         return (out, Ho, Wo, st) if stats else (out, Ho, Wo)
 
+    def store_dtype(self):
+        """Element type of the frame store's feature rows: bf16 in bf16 mode -- under autocast the reference's fmaps / pc_fvec are
+        bf16 tensors (model_utils.py:467-476) -- which halves the store, the correlation kernel's gather traffic and the
+        multi-GPU all-gather; fp32 in the fp32 / bf16x3 modes."""
+        return torch.bfloat16 if (self.precision == "bf16" and self.bf16_store) else torch.float32
+
     def _act_dtype(self, pk):
         """Element type of the encoder's intermediate activations: bf16 in bf16 mode (HBM-bound layers, bf16 MFMA operands)."""
         return torch.bfloat16 if (self.bf16_activations and self.precision == "bf16") else torch.float32
@@ -376,7 +383,7 @@ class MVTracker(nn.Module):
         V, T, _, H, W = rgbs.shape
         t1 = T if t1 is None else t1
         hs, ws = H // self.stride, W // self.stride
-        F0 = out if out is not None else torch.zeros(T, V, hs, ws, self.latent_dim, device=rgbs.device)
+        F0 = out if out is not None else torch.zeros(T, V, hs, ws, self.latent_dim, device=rgbs.device, dtype=self.store_dtype())
         flat = F0.view(-1, hs, ws, self.latent_dim)
         # (whole frames per chunk, as before: the chunk boundaries do not change any result, only the launch shapes)
         self.encode_images(rgbs, t0 * V, t1 * V, _Shifted(flat, out_t0 * V), images_per_chunk=max(1, images_per_chunk // V) * V)
@@ -416,9 +423,10 @@ class MVTracker(nn.Module):
         t1 = T if t1 is None else t1
         # (no memset of the 0.8 GB level-0 store: frames [t0, T) are written by the encoder before any window reads them --
         #  later frames possibly on the second stream, ordered by events -- and frames before t0 are never read)
-        fv = [torch.empty(T, V, hs, ws, C, device=dev) if level0 is None else level0]
+        sdt = level0.dtype if level0 is not None else self.store_dtype()
+        fv = [torch.empty(T, V, hs, ws, C, device=dev, dtype=sdt) if level0 is None else level0]
         for lvl in range(1, self.corr_n_levels):
-            fv.append(torch.empty(T, V, hs >> lvl, ws >> lvl, C, device=dev))
+            fv.append(torch.empty(T, V, hs >> lvl, ws >> lvl, C, device=dev, dtype=sdt))
         for f_ in fv[(1 if level0 is not None else 0):]:
             f_[:t0].zero_()
         self.fill_frame_features({"fvec": fv}, rgbs, t0, t1, level0)

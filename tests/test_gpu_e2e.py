@@ -146,8 +146,9 @@ def test_forward_vs_oracle_logits_and_late_queries(model, W):
     rel = ((r["traj_e"].cpu() - ref).abs().max() / ref.abs().max()).item()
     verr = (model.last_vis_logits.cpu() - ro["vis_logits"]).abs().max().item()
     # error relative to how far the tracks MOVE (the scene is ~4 m across, the seeded model moves a track ~0.2 m per clip)
-    q0 = args_of(clip)[2][0, :, 1:]
-    disp = (ref[0] - q0[None]).abs().max().item()
+    q0 = args_of(clip)[2][0]
+    live = (torch.arange(ref.shape[1])[:, None] >= q0[None, :, 0].long())  # (T,N): frames at / after the query frame
+    disp = ((ref[0] - q0[None, :, 1:]).abs().amax(-1) * live).max().item()
     rel_disp = (r["traj_e"].cpu() - ref).abs().max().item() / disp
     print(f"late-query clip: first neighbour flip {first_flip}, tracks rel {rel:.2e} (of the displacement {disp:.3f} m: {rel_disp:.2e}), "
           f"vis logits {verr:.2e}")

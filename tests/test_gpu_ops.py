@@ -1032,3 +1032,42 @@ def test_bf16_store_keeps_nan(hip):
     ok = torch.ones(M, dtype=torch.bool)
     ok[3] = ok[7] = False
     assert bool(torch.isfinite(o[ok]).all())
+
+
+# ----------------------------------------------------------------------------------------- round 2: bf16 frame store
+@pytest.mark.parametrize("C,K", [(128, 16), (32, 16), (64, 5), (256, 16)])
+def test_corr_gather_dot_bf16_rows(hip, C, K):
+    """bf16 feature rows (the frame store of bf16 mode): neighbour indices bit-exact, dots against the oracle evaluated on the
+    SAME bf16-rounded rows (the kernel accumulates the fp32 target x bf16 row products in fp32)."""
+    g = torch.Generator().manual_seed(C + K)
+    B, P, M = 3, 3000, 50
+    xyz = torch.rand(B, P, 3, generator=g) * 4 - 2
+    fvec = torch.randn(B, P, C, generator=g).bfloat16()
+    tg = torch.randn(B, M, C, generator=g)
+    cd = torch.rand(B, M, 3, generator=g) * 4 - 2
+    out, idx, _ = _run_corr(hip, xyz, fvec, tg, cd, K, 1)
+    ref, ridx = O.corr_sample(xyz, fvec.float(), tg, cd, K, 1, True, False, "exact", return_idx=True)
+    assert torch.equal(idx, ridx)
+    assert (out - ref).abs().max() < 2e-5
+
+
+def test_avgpool2_and_knn1_gather_bf16(hip):
+    g = torch.Generator().manual_seed(3)
+    n, h, w, C = 3, 10, 14, 128
+    x = torch.randn(n, h, w, C, generator=g).bfloat16()
+    out = torch.empty(n, h // 2, w // 2, C, device=DEV, dtype=torch.bfloat16)
+    hip.avgpool2(G(x), out, n, h, w, C)
+    xf = x.float()
+    ref = ((((xf[:, 0::2, 0::2] + xf[:, 0::2, 1::2]) + xf[:, 1::2, 0::2]) + xf[:, 1::2, 1::2]) * 0.25).bfloat16()
+    assert torch.equal(out.cpu(), ref)  # fp32 mean of the four bf16 values, one rounding
+    P, nq = 2000, 30
+    xyz = torch.zeros(2, P, 4)
+    xyz[..., :3] = torch.rand(2, P, 3, generator=g)
+    fvec = torch.randn(2, P, C, generator=g).bfloat16()
+    q = torch.rand(nq, 3, generator=g)
+    keys = torch.empty(nq, device=DEV, dtype=torch.int64)
+    hip.knn_scan(G(xyz), P, G(q), nq, 1, 1, 0, 2, 1, 1, keys)
+    feat = torch.empty(nq, C, device=DEV)
+    hip.knn1_gather(G(fvec), P, C, keys, nq, 1, 1, feat)
+    _, ridx = O.knn_exact(1, xyz[1:2, :, :3], q[None])
+    assert torch.equal(feat.cpu(), fvec[1][ridx[0, :, 0]].float())
