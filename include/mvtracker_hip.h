@@ -272,7 +272,7 @@ int mvt_knn_merge_levels(int levels, const mvt_knn_level* lv, int N, int S, int 
  * [N][S][K] int32 from mvt_knn_merge, P[l].  For k < K:
  *   out[(n*S+s)*ldo + o_off + l*4K + 4k + {0,1,2,3}] = { <target, f_k>/sqrt(C), xyz_k - coord }
  * (mvtracker.py:827-842 with corr_add_neighbor_offset=True; the level-major concat of :374).  targets [N][S][C] fp32.
- * fvec_bf16: the feature rows are bf16 (256-B rows at C = 128; the dot accumulates in fp32).  ldo, o_off multiples of 4. */
+ * fvec_bf16: the feature rows are bf16 (256-B rows at C = 128; the dot accumulates in fp32). */
 int mvt_corr_gather_dot(int levels, const float* const* xyz, const void* const* fvec, int fvec_bf16, const long long* P,
                         const int* const* idx, int C, const float* targets, const float* coords, int N, int S,
                         int frame0, int frame_step, int T, int K, float* out, int ldo, int o_off, void* stream);
@@ -332,6 +332,49 @@ int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, c
                        void* stream);
 /* x[(n*S+s)*ld + 0:C] = v[n][0:C] for all s  (virtual-token broadcast, blocks.py:458-459). */
 int mvt_broadcast_rows(const float* v, float* x, int ld, int n, int S, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Composite entry points: one C call per stage of the hot path instead of one per kernel, so that a
+ * non-Python caller can run the updater as ONE operation and the launch order lives in the library, not in host glue.
+ *
+ * mvt_updateformer_forward = EfficientUpdateFormer.forward (cotracker2/blocks.py:455-494) on the bf16 matrix cores for the
+ * shipped geometry (hidden 256, 6 heads x 48, MLP 1024, 64 virtual tracks; configs/model/mvtracker.yaml): input transform,
+ * virtual-token broadcast, depth x (time block, virtual<-point, virtual self, point<-virtual), flow head.
+ *   x     [n*S][ldx] fp32 tokens (K = token_dim columns used), track-major (row = track * S + frame)
+ *   delta [n*S][ldd] fp32, out_dim columns written
+ * Weights: device pointers prepared once by the caller -- `frag` = fragment-major bf16 of mvt_pack_frag_bf16, `rows` = row-major
+ * bf16 [N][ldw] (ldw = round_up(K, 64), zero padded) as mvt_gemm_bf16 takes them; biases / LayerNorm affines fp32.
+ * flow0 / flow2 must be packed with N rounded up to a multiple of 4 (zero rows, zero bias) so that the pad columns of the hidden
+ * activations -- read as K padding by the next layer -- are written as exact zeros by the GEMM itself.
+ * `workspace`: mvt_updateformer_workspace_bytes(n, S) bytes, 256-B aligned, no state carried between calls.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct mvt_lin_frag {
+  const unsigned short* w; /* fragment-major bf16 of [N][K] */
+  const float* b;          /* [N] */
+  int N, K;
+} mvt_lin_frag;
+typedef struct mvt_lin_rows {
+  const unsigned short* w; /* row-major bf16 [N][ldw] */
+  const float* b;
+  int N, K, ldw;
+} mvt_lin_rows;
+typedef struct mvt_updater_block {
+  mvt_lin_frag qkv;   /* self-attention blocks (time, virtual self): fused [q|k|v] projection, N = 3 * heads * dim_head */
+  mvt_lin_frag q, kv; /* cross-attention blocks: to_q on the block's own tokens, to_kv on the context tokens */
+  const float* ctx_ln_w; /* cross blocks: norm_context affine (eps 1e-5, cotracker2/blocks.py:314-315) */
+  const float* ctx_ln_b;
+  mvt_lin_frag out, fc1, fc2;
+} mvt_updater_block;
+#define MVT_UPDATER_MAX_DEPTH 8
+typedef struct mvt_updater_weights {
+  int depth, hidden, heads, dim_head, n_virtual, S, token_dim, out_dim;
+  const float* virtual_tokens; /* [n_virtual][hidden] */
+  mvt_lin_rows input_transform, flow0, flow2, flow4;
+  mvt_updater_block time_blk[MVT_UPDATER_MAX_DEPTH], v2p[MVT_UPDATER_MAX_DEPTH], vself[MVT_UPDATER_MAX_DEPTH], p2v[MVT_UPDATER_MAX_DEPTH];
+} mvt_updater_weights;
+long long mvt_updateformer_workspace_bytes(int n, int S); /* host; -1 on bad arguments */
+int mvt_updateformer_forward(const mvt_updater_weights* w /* host struct of device pointers */, const float* x, int ldx, int n,
+                             float* delta, int ldd, void* workspace, long long workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -475,7 +475,14 @@ __global__ __launch_bounds__(256) void corr_gather_dot_kernel(CorrLevels lv, con
   }
   if (lane < K) {
     float* o = out + row * ldo + o_off + level * K * 4 + lane * 4;
-    *reinterpret_cast<f32x4*>(o) = (f32x4){mine / scale, ox, oy, oz};
+    if ((((uintptr_t)out | (unsigned)(ldo * 4) | (unsigned)(o_off * 4)) & 15) == 0) {  // (uniform: the tracker's layout is aligned)
+      *reinterpret_cast<f32x4*>(o) = (f32x4){mine / scale, ox, oy, oz};
+    } else {
+      o[0] = mine / scale;
+      o[1] = ox;
+      o[2] = oy;
+      o[3] = oz;
+    }
   }
 }
 
@@ -657,7 +664,7 @@ extern "C" int mvt_corr_gather_dot(int levels, const float* const* xyz, const vo
                                    const int* const* idx, int C, const float* targets, const float* coords, int N, int S,
                                    int frame0, int frame_step, int T, int K, float* out, int ldo, int o_off, void* stream) {
   MVT_REQUIRE(levels >= 1 && levels <= 8 && xyz && fvec && P && idx && targets && coords && out);
-  MVT_REQUIRE((fvec_bf16 == 0 || fvec_bf16 == 1) && ldo % 4 == 0 && o_off % 4 == 0 && ((uintptr_t)out % 16 == 0));
+  MVT_REQUIRE((fvec_bf16 == 0 || fvec_bf16 == 1));
   MVT_REQUIRE(N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0 && K >= 1 && K <= 16);
   MVT_REQUIRE(o_off >= 0 && ldo >= o_off + levels * 4 * K);
   CorrLevels lv{};

@@ -69,8 +69,10 @@ SIGNATURES = {
     "mvt_attention": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, P],
     "mvt_attention_bf16": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, I, P, P],
     "mvt_broadcast_rows": [P, P, I, I, I, I, P],
+    "mvt_updateformer_workspace_bytes": [I, I],
+    "mvt_updateformer_forward": [P, P, I, I, P, I, P, LL, P],
 }
-_RET = {"mvt_build_arch": C.c_char_p}
+_RET = {"mvt_build_arch": C.c_char_p, "mvt_updateformer_workspace_bytes": C.c_longlong}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = header / library mismatch
@@ -404,3 +406,51 @@ def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, n
 
 def broadcast_rows(v, x, ld, n, S, Cc):
     _call("mvt_broadcast_rows", _ptr(v), _ptr(x), ld, n, S, Cc, _stream())
+
+
+# ------------------------------------------------------------------ composite entry points
+class LinFrag(C.Structure):
+    """mvt_lin_frag of include/mvtracker_hip.h."""
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("N", C.c_int), ("K", C.c_int)]
+
+
+class LinRows(C.Structure):
+    """mvt_lin_rows."""
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("ldw", C.c_int)]
+
+
+class UpdaterBlock(C.Structure):
+    """mvt_updater_block."""
+    _fields_ = [("qkv", LinFrag), ("q", LinFrag), ("kv", LinFrag), ("ctx_ln_w", C.c_void_p), ("ctx_ln_b", C.c_void_p),
+                ("out", LinFrag), ("fc1", LinFrag), ("fc2", LinFrag)]
+
+
+UPDATER_MAX_DEPTH = 8
+COMPOSITE = True  # (the CPU host-logic tests, which replace the kernels one by one, switch the composite calls off)
+
+
+class UpdaterWeights(C.Structure):
+    """mvt_updater_weights: host struct of device pointers (the tensors must outlive it: keep them referenced)."""
+    _fields_ = [("depth", C.c_int), ("hidden", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int), ("n_virtual", C.c_int),
+                ("S", C.c_int), ("token_dim", C.c_int), ("out_dim", C.c_int), ("virtual_tokens", C.c_void_p),
+                ("input_transform", LinRows), ("flow0", LinRows), ("flow2", LinRows), ("flow4", LinRows),
+                ("time_blk", UpdaterBlock * UPDATER_MAX_DEPTH), ("v2p", UpdaterBlock * UPDATER_MAX_DEPTH),
+                ("vself", UpdaterBlock * UPDATER_MAX_DEPTH), ("p2v", UpdaterBlock * UPDATER_MAX_DEPTH)]
+
+
+def lin_frag(frag, bias, N, K):
+    return LinFrag(_ptr(frag), _ptr(bias), N, K)
+
+
+def lin_rows(w_hi, bias, N, K):
+    return LinRows(_ptr(w_hi), _ptr(bias), N, K, w_hi.shape[1])
+
+
+def updateformer_workspace_bytes(n, S) -> int:
+    return int(_lib.mvt_updateformer_workspace_bytes(n, S))
+
+
+def updateformer_forward(weights: UpdaterWeights, x, ldx, n, delta, ldd, workspace):
+    """EfficientUpdateFormer.forward as one library call (bf16 mode, shipped geometry); workspace: uint8 device tensor."""
+    _call("mvt_updateformer_forward", C.addressof(weights), _ptr(_f32c(x)), ldx, n, _ptr(delta), ldd, _ptr(workspace), workspace.numel(),
+          _stream())

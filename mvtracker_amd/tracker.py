@@ -274,12 +274,64 @@ class MVTracker(nn.Module):
                 for nme in (".cross_attn.to_q", ".cross_attn.to_kv", ".cross_attn.to_out", ".mlp.fc1", ".mlp.fc2"):
                     lin(p + nme)
         pk["virtual"] = sd[u + "virual_tracks"].reshape(self.nv, self.hidden).contiguous()
+        if self._composite_updater_ok():
+            pk["updater_struct"] = self._updater_struct(pk, sd, matrix)
         pk["ffeats_norm"] = (sd["ffeats_norm.weight"].contiguous(), sd["ffeats_norm.bias"].contiguous())
         lin("ffeats_updater.0")
         pk["vis"] = (sd["vis_predictor.0.weight"].reshape(-1).contiguous(), sd["vis_predictor.0.bias"].contiguous())
         pk["time_embed"] = self._time_embed_host.to(dev)
         self._packed, self._packed_sig = pk, sig
         return pk
+
+    def _composite_updater_ok(self):
+        """mvt_updateformer_forward covers the shipped geometry in bf16 mode with bf16 q/k/v tensors."""
+        return (self.precision == "bf16" and self.hidden == 256 and self.num_heads == 6 and self.dim_head == 48 and self.nv == 64
+                and self.latent_dim == 128 and self.fuse_blocks and self.mfma_attention and self.bf16_tokens
+                and self.depth <= hip.UPDATER_MAX_DEPTH and hip.COMPOSITE and os.environ.get("MVT_COMPOSITE", "1") != "0")
+
+    def _updater_struct(self, pk, sd, matrix):
+        """mvt_updater_weights (host struct of device pointers into ``pk``) for mvt_updateformer_forward."""
+        u = "updateformer."
+        h, inner = self.hidden, self.num_heads * self.dim_head
+        w = hip.UpdaterWeights()
+        w.depth, w.hidden, w.heads, w.dim_head, w.n_virtual, w.S = self.depth, h, self.num_heads, self.dim_head, self.nv, self.S
+        w.token_dim, w.out_dim = self.updateformer_input_dim, self.out_dim
+        w.virtual_tokens = pk["virtual"].data_ptr()
+        keep = []  # tensors referenced by the struct only
+
+        def rows(name, pad_n=False):
+            wt, b = sd[name + ".weight"], sd[name + ".bias"]
+            n, k = wt.shape
+            if pad_n and n % 4:  # zero rows + zero bias: the GEMM itself writes the pad columns of the hidden activations as zeros
+                n4 = _round_up(n, 4)
+                wt = torch.cat([wt, torch.zeros(n4 - n, k, device=wt.device)], 0)
+                b = torch.cat([b, torch.zeros(n4 - n, device=b.device)], 0)
+            hi = matrix(wt)[0]
+            b = b.contiguous()
+            keep.extend([hi, b])
+            return hip.lin_rows(hi, b, wt.shape[0], k)
+
+        w.input_transform = rows(u + "input_transform")
+        w.flow0, w.flow2, w.flow4 = rows(u + "flow_head.0", True), rows(u + "flow_head.2", True), rows(u + "flow_head.4")
+
+        def frag(name):
+            _, b, n, k = pk[name]
+            return hip.lin_frag(pk[name + "#frag"], b, n, k)
+
+        for i in range(self.depth):
+            for arr, blk, attn, cross in ((w.time_blk, "time_blocks", "attn", False), (w.vself, "space_virtual_blocks", "attn", False),
+                                          (w.v2p, "space_virtual2point_blocks", "cross_attn", True),
+                                          (w.p2v, "space_point2virtual_blocks", "cross_attn", True)):
+                p = f"{u}{blk}.{i}"
+                b = arr[i]
+                if cross:
+                    b.q, b.kv = frag(f"{p}.{attn}.to_q"), frag(f"{p}.{attn}.to_kv")
+                    b.ctx_ln_w, b.ctx_ln_b = (t_.data_ptr() for t_ in pk[p + ".norm_context"])
+                else:
+                    b.qkv = frag(f"{p}.{attn}.qkv")
+                b.out, b.fc1, b.fc2 = frag(f"{p}.{attn}.to_out"), frag(p + ".mlp.fc1"), frag(p + ".mlp.fc2")
+        pk["updater_struct_keep"] = keep
+        return w
 
     # ------------------------------------------------------------------ encoder (reference spatracker/blocks.py:214-284)
     def _conv(self, pk, name, x, n, H, W, cin, cout, k, stride, pad, out=None, ldo=None, in_stats=None, stats=False):
@@ -489,6 +541,10 @@ class MVTracker(nn.Module):
         self._lin(pk, p + ".mlp.fc2", hbuf, 4 * h, rows, tok, h, R=tok, ldr=h)
 
     def _update_former(self, pk, x, ldx, n, delta, ldd):
+        if "updater_struct" in pk:  # the whole transformer as ONE library call (mvt_updateformer_forward)
+            nbytes = hip.updateformer_workspace_bytes(n, self.S)
+            ws = self._workspace(nbytes, x.device)
+            return hip.updateformer_forward(pk["updater_struct"], x, ldx, n, delta, ldd, ws)
         if self.precision == "bf16" and self.hidden == 256 and self.num_heads * self.dim_head == 288 and self.fuse_blocks:
             return self._update_former_fused(pk, x, ldx, n, delta, ldd)
         S, h, nv, H, dh = self.S, self.hidden, self.nv, self.num_heads, self.dim_head
@@ -541,6 +597,15 @@ class MVTracker(nn.Module):
         self._lin(pk, u + "flow_head.0", pt, h, Mp, h1, ldh, hip.ACT_RELU)
         self._lin(pk, u + "flow_head.2", h1, ldh, Mp, h2, ldh, hip.ACT_RELU)
         self._lin(pk, u + "flow_head.4", h2, ldh, Mp, delta, ldd)
+
+    def _workspace(self, nbytes, dev):
+        """Device scratch of the composite entry points (no state between calls; grown on demand, one per device and stream)."""
+        key = ("ws", dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        t = self._scratch.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(_round_up(nbytes, 1 << 20), device=dev, dtype=torch.uint8)
+            self._scratch[key] = t
+        return t
 
     def _flow_scratch(self, rows, ld, dev):
         """Hidden activations of the flow head, (rows, ld) with ld = round_up(out_dim, 4): the GEMMs write out_dim columns, the

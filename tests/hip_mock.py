@@ -417,3 +417,4 @@ def install(monkeypatch):
                  "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))
+    monkeypatch.setattr(hip, "COMPOSITE", False)  # the per-kernel sequencing is what these tests exercise
