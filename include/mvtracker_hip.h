@@ -155,6 +155,25 @@ int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 whe
                                              launches cut over 4x more workgroups (deterministic partial sums) */,
                          void* stream);
 
+/* mvt_block_fused_bf16 with the attention that precedes the block computed INSIDE the kernel (no attention launch, no
+ * attention tensor in HBM); heads = 6, dim_head = 48.  x rows are track-major, row = token * S + frame.
+ *   MVT_ATTN_TIME  (AttnBlock over time, cotracker2/blocks.py:464-467): every token attends over its own S <= 32 frames;
+ *                  q, k, v [M][ld] bf16 indexed by the block's rows.
+ *   MVT_ATTN_FRAME (CrossAttnBlock / AttnBlock over space, blocks.py:477-483): the tokens of frame t attend over the
+ *                  n_keys <= 64 context tokens of frame t; q [M][ldq] indexed by the block's rows, k / v [n_keys * S][ldkv]
+ *                  with context token j of frame t at row j * S + t.  M < 4096: two-launch split path, workspace required. */
+#define MVT_ATTN_TIME 1
+#define MVT_ATTN_FRAME 2
+typedef struct mvt_block_attn {
+  int kind, S, n_keys, heads, dim_head, ldq, ldkv;
+  const unsigned short* q;
+  const unsigned short* k;
+  const unsigned short* v;
+} mvt_block_attn;
+int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn* attn, const unsigned short* wo, const float* bo,
+                              const unsigned short* w1, const float* b1, const unsigned short* w2, const float* b2, int H,
+                              const mvt_block_next* next, int n_next, long long M, int C, float* workspace, void* stream);
+
 /* LayerNorm + projections only (x is read, never written): y_i = LayerNorm_i(x) . Wn_i^T + bn_i with the mvt_block_next
  * descriptors of mvt_block_fused_bf16 -- the first q|k|v projection of an updater call. */
 int mvt_ln_proj_bf16(const float* x, int ldx, const mvt_block_next* next, int n_next, long long M, int C, void* stream);
@@ -368,6 +387,8 @@ typedef struct mvt_updater_block {
 #define MVT_UPDATER_MAX_DEPTH 8
 typedef struct mvt_updater_weights {
   int depth, hidden, heads, dim_head, n_virtual, S, token_dim, out_dim;
+  int fuse_attention; /* bit 0: time attention, bit 1: point<-virtual, bit 2: virtual self attention run inside the block kernels
+                         (mvt_attn_block_fused_bf16) instead of as separate launches; results are bit-identical either way */
   const float* virtual_tokens; /* [n_virtual][hidden] */
   mvt_lin_rows input_transform, flow0, flow2, flow4;
   mvt_updater_block time_blk[MVT_UPDATER_MAX_DEPTH], v2p[MVT_UPDATER_MAX_DEPTH], vself[MVT_UPDATER_MAX_DEPTH], p2v[MVT_UPDATER_MAX_DEPTH];

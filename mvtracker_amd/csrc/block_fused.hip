@@ -62,6 +62,11 @@ struct BlockArgs {
   int att_bf16;              // att is a bf16 tensor
   long long M;
   float* ws;                 // split path (small M): [M][C] x after the projection, then [H/256][M][C] partial MLP outputs
+  // in-kernel attention (ATT != 0): bf16 q / k / v operands, see mvt_block_attn
+  const unsigned short* aq;
+  const unsigned short* ak;
+  const unsigned short* av;
+  int ldaq, ldakv, S, nkeys, bmv;
 };
 
 __device__ __forceinline__ bf16x8 ldg_frag(const unsigned short* p) {
@@ -166,6 +171,153 @@ __device__ __forceinline__ void fill_wq(bf16x8 (&wq)[PFQ], const unsigned short*
   for (int j = 0; j < PFQ; ++j) wq[j] = ldg_frag(wrow + j * FS);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// In-kernel attention (head width 48): ONE wave computes softmax(Q K^T / sqrt(48)) V for up to 32 * NMBQ queries and
+// 32 * NKB keys of one head and leaves the bf16 result in the workgroup's attention tile As[row][hd*48 + d] -- the B operand
+// of the output projection -- instead of a separate attention launch writing it to HBM and this kernel reading it back.
+// Same arithmetic, in the same order, as attention_mfma_kernel<1> (attention_mfma.hip): S^T = K . Q^T on the MFMA, online
+// softmax over the accumulator registers, O^T += V^T . P^T with P^T taken from the accumulator and V^T from a small
+// transposed LDS image, so the fused and the unfused paths agree bit for bit.
+//   qrow(i) / krow(j): element row of query i / key j in q / k|v;  vt: this wave's V^T image [48][LDVA];  zrow: >= 40 zero
+//   elements (the d padding rows 48..63 of the second 32-row block);  arow0: tile row of query 0.
+constexpr int LDVA = 40, DHA = 48, VTA = DHA * LDVA;
+template <int NMBQ, int NKB, class QR, class KR>
+__device__ __forceinline__ void wave_attention(const unsigned short* __restrict__ q, int ldq, QR qrow, int nq,
+                                               const unsigned short* __restrict__ k, const unsigned short* __restrict__ v, int ldkv,
+                                               KR krow, int nk, int hd, unsigned short* vt, const unsigned short* zrow,
+                                               unsigned short* As, int lda, int arow0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float scale = 1.0f / sqrtf((float)DHA);
+  bf16x8 qf[NMBQ][3];
+#pragma unroll
+  for (int mb = 0; mb < NMBQ; ++mb) {
+    const int qi = mb * 32 + r;
+    const long long qo = qrow(qi < nq ? qi : nq - 1) * (long long)ldq + hd * DHA;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      f32x4 a = load_act4(reinterpret_cast<const float*>(q), qo + ks * 16 + 8 * h, 1);
+      f32x4 b = load_act4(reinterpret_cast<const float*>(q), qo + ks * 16 + 8 * h + 4, 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] *= scale;
+        b[e] *= scale;
+      }
+      const bf16x4 x = __builtin_convertvector(a, bf16x4), y = __builtin_convertvector(b, bf16x4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qf[mb][ks][e] = x[e];
+        qf[mb][ks][4 + e] = y[e];
+      }
+    }
+  }
+  f32x16 oacc[NMBQ][2];
+  float m[NMBQ], l[NMBQ];
+#pragma unroll
+  for (int mb = 0; mb < NMBQ; ++mb) {
+    m[mb] = -INFINITY;
+    l[mb] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[mb][db][e] = 0.f;
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int key = kb * 32 + r;
+    const long long ko = krow(key < nk ? key : nk - 1) * (long long)ldkv + hd * DHA;
+    bf16x8 kf[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) kf[ks] = ldg_frag(k + ko + ks * 16 + 8 * h);
+    {
+      const long long vo = ko + 24 * h;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        u32x2 w = *reinterpret_cast<const u32x2*>(v + vo + 4 * i);
+        if (key >= nk) w = (u32x2){0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vt[(24 * h + 4 * i + e) * LDVA + r] = (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xFFFFu));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+#pragma unroll
+    for (int mb = 0; mb < NMBQ; ++mb) {
+      f32x16 sc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[mb][ks], sc, 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kk = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (kk >= nk) sc[e] = -INFINITY;
+        mx = fmaxf(mx, sc[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[mb], mx);
+      const float corr = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        sc[e] = __expf(sc[e] - mn);
+        ps += sc[e];
+      }
+      l[mb] = l[mb] * corr + ps;
+      m[mb] = mn;
+      if (__ballot(corr != 1.0f)) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[mb][db][e] *= corr;
+      }
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        f32x4 lo4, hi4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo4[e] = sc[8 * sk + e];
+          hi4[e] = sc[8 * sk + 4 + e];
+        }
+        const bf16x4 bl = __builtin_convertvector(lo4, bf16x4), bh = __builtin_convertvector(hi4, bf16x4);
+        bf16x8 pb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pb[e] = bl[e];
+          pb[4 + e] = bh[e];
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const unsigned short* vr = (db * 32 + r < DHA) ? &vt[(db * 32 + r) * LDVA + 16 * sk + 4 * h] : zrow + 16 * sk + 4 * h;
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(vr), a1 = *reinterpret_cast<const u32x2*>(vr + 8);
+          const bf16x8 va = __builtin_bit_cast(bf16x8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
+          oacc[mb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, oacc[mb][db], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < NMBQ; ++mb) {
+    const float lt = l[mb] + __shfl_xor(l[mb], 32, 64);
+    const float inv = 1.0f / lt;
+    const int qi = mb * 32 + r;
+    if (qi >= nq) continue;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = db * 32 + 8 * gq + 4 * h;
+        if (d < DHA) {
+          f32x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = oacc[mb][db][4 * gq + e] * inv;
+          *reinterpret_cast<u32x2*>(&As[(arow0 + qi) * lda + hd * DHA + d]) = __builtin_bit_cast(u32x2, __builtin_convertvector(t, bf16x4));
+        }
+      }
+    }
+  }
+}
+
 // LayerNorm of the 128 x C tile held as accumulators v[4][16] (wave w: channels w*32 .. +31 of every token), written
 // as bf16 into Xs.  st: LDS scratch [8 waves][128 tokens][2].  Optional affine (wave's channel slice).
 template <int NMB>
@@ -221,7 +373,13 @@ __device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short
 // per chunk, it is cheap), ONE 256-unit chunk of the MLP, partial fc2 output -> ws.  Pass 2 (grid.y = column slice):
 // x = x_mid + b2 + sum of the partials in fixed order (deterministic), then the follow-up projections, 8 column blocks per
 // workgroup.  Each workgroup streams a quarter of the weights, four times as many CUs pull them.
-template <int NMB, int MODE>
+// ATT: the attention that precedes the block runs INSIDE the kernel (wave_attention) instead of as its own launch:
+//   1  time attention (cotracker2/blocks.py:464-467): a tile = p.bmv / S whole tracks (60 rows = 5 tracks at S = 12); the
+//      S x S attention of every (track, head) is one wave_attention unit, units dealt round-robin to the 8 waves;
+//   2  per-frame attention against p.nkeys <= 64 context tokens of the same frame (point<-virtual cross attention,
+//      virtual self attention; blocks.py:477-483): the tile is FRAME-MAJOR -- tokens blockIdx.x*BM .. +BM-1 of frame blockIdx.z,
+//      i.e. rows token*S + frame -- so that all its queries share one K / V set; one wave per head.
+template <int NMB, int MODE, int ATT>
 __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   using K_ = Cfg<NMB>;
   constexpr int BM = K_::BM, HC = K_::HC, LDH = K_::LDH, LDA = K_::LDA;
@@ -232,7 +390,22 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
-  const long long m0 = (long long)blockIdx.x * BM;
+  static_assert(ATT == 0 || MODE != 2, "pass 2 of the split path has no attention");
+  const int bmv = ATT == 1 ? p.bmv : BM;                      // rows of the tile that hold tokens
+  const long long m0 = ATT == 2 ? 0 : (long long)blockIdx.x * bmv;
+  const long long ntok = ATT == 2 ? p.M / p.S : 0;             // ATT 2: tokens per frame
+  // global row of tile row i (-1: none)
+  auto grow = [&](int i) -> long long {
+    if (ATT == 2) {
+      const long long tk = (long long)blockIdx.x * BM + i;
+      return tk < ntok ? tk * p.S + (long long)blockIdx.z : -1;
+    }
+    const long long m = m0 + i;
+    return (i < bmv && m < p.M) ? m : -1;
+  };
+  // rows [rlo, rhi) bound the tile (workgroup-uniform)
+  const long long rlo = ATT == 2 ? (long long)blockIdx.x * BM * p.S : m0;
+  const long long rhi = ATT == 2 ? ((long long)blockIdx.x * BM + BM) * p.S : m0 + bmv;
   if (MODE != 2)
     for (int i = t; i < p.H; i += NT) b1s[i] = p.b1[i];
   const long long MC = p.M * (long long)C;
@@ -245,15 +418,47 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     for (int e = 0; e < 16; ++e) v[mb][e] = 0.f;
 
   // ---- 1. attention output projection (accumulated into v, x is added afterwards)
-  if (MODE != 2 && p.att) {
+  if (MODE != 2 && ATT != 0) {
+    unsigned short* As = &Hs[0][0];
+    // V^T images of the waves: Xs is idle until the first LayerNorm (NMB 2: all eight fit; NMB 1: four there, two behind As);
+    // the zero row (d padding) lives in the LayerNorm scratch, equally idle
+    unsigned short* zrow = reinterpret_cast<unsigned short*>(st);
+    if (t < 48) zrow[t] = 0;
+    constexpr int XW = (BM * LDX) / VTA;  // images that fit Xs
+    unsigned short* vt = wave < XW ? &Xs[wave * VTA] : &Hs[0][0] + ((BM * LDA + 7) & ~7) + (wave - XW) * VTA;
+    static_assert(XW + (2 * BM * LDH - BM * LDA - 8) / VTA >= 6, "six V^T images fit beside the attention tile");
+    __syncthreads();
+    if (ATT == 1) {
+      const int ntr = bmv / p.S;
+      for (int u = wave; u < ntr * 6; u += 8) {
+        const int tr = u / 6, hd = u - tr * 6;
+        const long long mt = m0 + (long long)tr * p.S;  // first row of the track
+        if (mt >= p.M) continue;
+        auto row = [&](int i) { return mt + i; };
+        wave_attention<1, 1>(p.aq, p.ldaq, row, p.S, p.ak, p.av, p.ldakv, row, p.S, hd, vt, zrow, As, LDA, tr * p.S, lane);
+      }
+    } else if (wave < 6 && grow(0) >= 0) {
+      const long long left = ntok - (long long)blockIdx.x * BM;
+      const int nq = left < BM ? (int)left : BM;
+      auto qrow = [&](int i) { return ((long long)blockIdx.x * BM + i) * p.S + (long long)blockIdx.z; };
+      auto krow = [&](int j) { return (long long)j * p.S + (long long)blockIdx.z; };
+      wave_attention<NMB, 2>(p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, vt, zrow, As, LDA, 0, lane);
+    }
+    __syncthreads();
+    gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[mb][e] += p.bo[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+  } else if (MODE != 2 && p.att) {
     // att tile (fp32) -> bf16 [128][296], overlaid on the two (still unused) H buffers
     unsigned short* As = &Hs[0][0];
     const int q4 = p.Ko / 4;  // float4 per row
     for (int f = t; f < BM * q4; f += NT) {
       const int row = f / q4, c = (f - row * q4) * 4;
-      const long long m = m0 + row;
+      const long long m = grow(row);
       u32x2 w = (u32x2){0u, 0u};
-      if (m < p.M) {
+      if (m >= 0) {
         if (p.att_bf16) {
           w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.att) + m * (long long)p.ldatt + c);
         } else {
@@ -272,12 +477,12 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   }
 #pragma unroll
   for (int mb = 0; mb < NMB; ++mb) {
-    const long long m = m0 + mb * 32 + r;
+    const long long m = grow(mb * 32 + r);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (MODE == 2 && p.ws) {  // x after the projection (pass 1) + b2 + the MLP partials, in chunk order
-        if (m < p.M) {
+        if (m >= 0) {
           const long long o = m * C + wave * 32 + 8 * g + 4 * h;
           xv = *reinterpret_cast<const f32x4*>(p.ws + o);
           for (int sidx = 0; sidx < p.H / Cfg<NMB>::HC; ++sidx) {
@@ -288,7 +493,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) xv[e] += p.b2[wave * 32 + 8 * g + 4 * h + e];
-      } else if (m < p.M) {  // (MODE 2 without a workspace = mvt_ln_proj_bf16: x is final and only read; ws / b2 are null there)
+      } else if (m >= 0) {  // (MODE 2 without a workspace = mvt_ln_proj_bf16: x is final and only read; ws / b2 are null there)
         xv = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
       }
 #pragma unroll
@@ -301,8 +506,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   auto store_x = [&]() {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
-      const long long m = m0 + mb * 32 + r;
-      if (m < p.M) {
+      const long long m = grow(mb * 32 + r);
+      if (m >= 0) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 o;
@@ -316,7 +521,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   if (MODE != 2) ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
   bf16x8 wq[PFQ];  // the weight-fragment queue, chained through the MLP and the follow-up projections
   // a projection runs in this workgroup when its row range meets the workgroup's rows (workgroup-uniform)
-  auto active = [&](int q) { return q < p.n_next && m0 < p.next[q].row_hi && m0 + BM > p.next[q].row_lo; };
+  auto active = [&](int q) { return q < p.n_next && rlo < p.next[q].row_hi && rhi > p.next[q].row_lo; };
   const bool tail_next = MODE == 0 && active(0) && wave < (p.next[0].N + 31) / 32;
   if (MODE != 2) {
     f32x16 acc2[NMB];
@@ -371,8 +576,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     if (MODE == 1) {  // partial fc2 output of this chunk (+ x after the projection, once) -> workspace; pass 2 finishes
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
-        const long long m = m0 + mb * 32 + r;
-        if (m >= p.M) continue;
+        const long long m = grow(mb * 32 + r);
+        if (m < 0) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const long long o = m * C + wave * 32 + 8 * g + 4 * h;
@@ -447,16 +652,16 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
         for (int k = 0; k < NMB * 2; ++k) {
           const int pc = lane + 64 * k, row = pc >> 2, c = pc & 3;
-          const long long m = m0 + row;
-          if (m < p.M && m >= nx.row_lo && m < nx.row_hi)
+          const long long m = grow(row);
+          if (m >= nx.row_lo && m < nx.row_hi)
             *reinterpret_cast<u32x4*>(yb + m * (long long)nx.ldy + c * 8) = *reinterpret_cast<const u32x4*>(&tile[row * YLD + c * 8]);
         }
         continue;
       }
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
-        const long long m = m0 + mb * 32 + r;
-        if (m >= p.M || m < nx.row_lo || m >= nx.row_hi) continue;
+        const long long m = grow(mb * 32 + r);
+        if (m < nx.row_lo || m >= nx.row_hi) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = nb * 32 + 8 * g + 4 * h;
@@ -530,17 +735,68 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const void* att, int att_
   static const bool no_split = getenv("MVT_BLOCK_NOSPLIT") != nullptr;
   a.ws = workspace;
   if (nmb == 2) {
-    hipLaunchKernelGGL((block_fused_bf16<2, 0>), dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
+    hipLaunchKernelGGL((block_fused_bf16<2, 0, 0>), dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
   } else if (workspace && !no_split && M <= 2048) {
     MVT_REQUIRE((uintptr_t)workspace % 16 == 0);
     const unsigned tiles = (unsigned)mvt_cdiv(M, 32);
-    hipLaunchKernelGGL((block_fused_bf16<1, 1>), dim3(tiles, (unsigned)(H / 256)), dim3(NT), 0, mvt_stream(stream), a);
+    hipLaunchKernelGGL((block_fused_bf16<1, 1, 0>), dim3(tiles, (unsigned)(H / 256)), dim3(NT), 0, mvt_stream(stream), a);
     int maxblk = 1;
     for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
     const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
-    hipLaunchKernelGGL((block_fused_bf16<1, 2>), dim3(tiles, slices), dim3(NT), 0, mvt_stream(stream), a);
+    hipLaunchKernelGGL((block_fused_bf16<1, 2, 0>), dim3(tiles, slices), dim3(NT), 0, mvt_stream(stream), a);
   } else {
-    hipLaunchKernelGGL((block_fused_bf16<1, 0>), dim3((unsigned)mvt_cdiv(M, 32)), dim3(NT), 0, mvt_stream(stream), a);
+    hipLaunchKernelGGL((block_fused_bf16<1, 0, 0>), dim3((unsigned)mvt_cdiv(M, 32)), dim3(NT), 0, mvt_stream(stream), a);
+  }
+  return mvt_launch_status();
+}
+
+// The block with its attention inside (ATT 1 / 2 of block_fused_bf16).
+extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn* attn, const unsigned short* wo, const float* bo,
+                                         const unsigned short* w1, const float* b1, const unsigned short* w2, const float* b2, int H,
+                                         const mvt_block_next* next, int n_next, long long M, int Cc, float* workspace, void* stream) {
+  MVT_REQUIRE(x && attn && wo && bo && w1 && b1 && w2 && b2 && M > 0 && Cc == C && H > 0 && H % 256 == 0 && H <= 4 * C);
+  MVT_REQUIRE(ldx % 4 == 0 && ldx >= C && n_next >= 0 && n_next <= MVT_BLOCK_MAX_NEXT && (n_next == 0 || next));
+  MVT_REQUIRE(attn->q && attn->k && attn->v && attn->heads == 6 && attn->dim_head == DHA && attn->S >= 1 && M % attn->S == 0);
+  MVT_REQUIRE(attn->ldq % 8 == 0 && attn->ldkv % 8 == 0 && attn->ldq >= 288 && attn->ldkv >= 288);
+  MVT_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)wo % 16 == 0) && ((uintptr_t)w1 % 16 == 0) && ((uintptr_t)w2 % 16 == 0));
+  MVT_REQUIRE(((uintptr_t)attn->q % 16 == 0) && ((uintptr_t)attn->k % 16 == 0) && ((uintptr_t)attn->v % 16 == 0));
+  BlockArgs a{};
+  a.x = x; a.ldx = ldx; a.att = nullptr; a.Ko = 288; a.wo = wo; a.bo = bo; a.ldwo = 288;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.ldw1 = C; a.ldw2 = H; a.H = H; a.M = M; a.n_next = n_next; a.ws = workspace;
+  a.aq = attn->q; a.ak = attn->k; a.av = attn->v; a.ldaq = attn->ldq; a.ldakv = attn->ldkv; a.S = attn->S; a.nkeys = attn->n_keys;
+  for (int q = 0; q < n_next; ++q) {
+    const mvt_block_next& nx = next[q];
+    MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
+    MVT_REQUIRE((nx.y_bf16 == 0 || nx.y_bf16 == 1) && (nx.lnw == nullptr) == (nx.lnb == nullptr));
+    MVT_REQUIRE(((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0) && nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo));
+    a.next[q] = nx;
+    if (nx.row_hi == 0) a.next[q].row_hi = M;
+  }
+  const int S = attn->S;
+  if (attn->kind == MVT_ATTN_TIME) {
+    // tiles of whole tracks: S <= 32 keys per track (one MFMA key block), 64 / S tracks per 64-row tile
+    MVT_REQUIRE(S <= 32 && !workspace);
+    a.bmv = (64 / S) * S;
+    hipLaunchKernelGGL((block_fused_bf16<2, 0, 1>), dim3((unsigned)mvt_cdiv(M, a.bmv)), dim3(NT), 0, mvt_stream(stream), a);
+  } else if (attn->kind == MVT_ATTN_FRAME) {
+    MVT_REQUIRE(attn->n_keys >= 1 && attn->n_keys <= 64);
+    const long long ntok = M / S;
+    if (ntok * S >= 4096) {
+      MVT_REQUIRE(!workspace);
+      hipLaunchKernelGGL((block_fused_bf16<2, 0, 2>), dim3((unsigned)mvt_cdiv(ntok, 64), 1, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
+    } else {
+      // few rows (the 64 virtual tracks): two-launch split path; pass 1 (frame-major tiles, attention recomputed by each of the
+      // H / 256 chunk workgroups: it is tiny) leaves x and the MLP partials in the workspace by GLOBAL row, pass 2 is unchanged
+      MVT_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && M <= 2048);
+      hipLaunchKernelGGL((block_fused_bf16<1, 1, 2>), dim3((unsigned)mvt_cdiv(ntok, 32), (unsigned)(H / 256), (unsigned)S), dim3(NT), 0,
+                         mvt_stream(stream), a);
+      int maxblk = 1;
+      for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
+      const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
+      hipLaunchKernelGGL((block_fused_bf16<1, 2, 0>), dim3((unsigned)mvt_cdiv(M, 32), slices), dim3(NT), 0, mvt_stream(stream), a);
+    }
+  } else {
+    return MVT_ERR_ARG;
   }
   return mvt_launch_status();
 }
@@ -562,7 +818,7 @@ extern "C" int mvt_ln_proj_bf16(const float* x, int ldx, const mvt_block_next* n
     if (nx.row_hi == 0) a.next[q].row_hi = M;
     maxblk = (nx.N + 31) / 32 > maxblk ? (nx.N + 31) / 32 : maxblk;
   }
-  hipLaunchKernelGGL((block_fused_bf16<1, 2>), dim3((unsigned)mvt_cdiv(M, 32), (unsigned)mvt_cdiv(maxblk, 8)), dim3(NT), 0, mvt_stream(stream),
+  hipLaunchKernelGGL((block_fused_bf16<1, 2, 0>), dim3((unsigned)mvt_cdiv(M, 32), (unsigned)mvt_cdiv(maxblk, 8)), dim3(NT), 0, mvt_stream(stream),
                      a);
   return mvt_launch_status();
 }

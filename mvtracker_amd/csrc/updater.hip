@@ -100,6 +100,14 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
     return mvt_block_fused_bf16(xr, H_, a, 1, INNER, INNER, b.out.w, INNER, b.out.b, b.fc1.w, H_, b.fc1.b, b.fc2.w, MLP, b.fc2.b, MLP, nx,
                                 nn, rows, H_, ws, stream);
   };
+  // the same block with its attention computed inside the kernel
+  auto attn_block = [&](const mvt_updater_block& b, float* xr, long long rows, int kind, const unsigned short* q, int ldq,
+                        const unsigned short* k, const unsigned short* v, int nkeys, const mvt_block_next* nx, int nn, float* ws) {
+    mvt_block_attn at{};
+    at.kind = kind; at.S = S; at.n_keys = nkeys; at.heads = HEADS; at.dim_head = DH_; at.ldq = ldq; at.ldkv = ld3; at.q = q; at.k = k; at.v = v;
+    return mvt_attn_block_fused_bf16(xr, H_, &at, b.out.w, b.out.b, b.fc1.w, b.fc1.b, b.fc2.w, b.fc2.b, MLP, nx, nn, rows, H_, ws, stream);
+  };
+  const bool fuse_time = (w->fuse_attention & 1) && S <= 32, fuse_p2v = (w->fuse_attention & 2) != 0, fuse_vs = (w->fuse_attention & 4) != 0;
 
   // tokens: input transform of the point rows, learned virtual tokens repeated over the S frames (blocks.py:456-459)
   MVT_TRY(mvt_gemm_bf16(x, ldx, w->input_transform.w, nullptr, w->input_transform.ldw, w->input_transform.b, nullptr, 0, tok, H_, (int)Mp, H_,
@@ -113,12 +121,18 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
     const bool last = i + 1 == w->depth;
     const mvt_updater_block &tb = w->time_blk[i], &v2p = w->v2p[i], &vs = w->vself[i], &p2v = w->p2v[i];
     // ---- time attention over the S frames of every (point or virtual) track; group = track, item stride 1 row
-    MVT_TRY(mvt_attention_bf16(qkv, ld3, S, 1, qkv + INNER, qkv + 2 * INNER, ld3, S, 1, att, INNER, n + NV, S, S, HEADS, DH_, BF, nullptr,
-                               stream));
     {
+      // (fused: the tile's own q|k|v rows are read before its epilogue overwrites them with the v2p projections -- every
+      //  workgroup owns whole tracks, and a tile's projection stores follow its attention)
       const mvt_block_next nx[3] = {next_of(v2p.kv, qkv + INNER, ld3, 0, Mp, v2p.ctx_ln_w, v2p.ctx_ln_b, 1e-5f),
                                     next_of(p2v.q, qp, INNER, 0, Mp), next_of(v2p.q, qkv, ld3, Mp, M)};
-      MVT_TRY(block(tb, tok, M, att, nx, 3, nullptr));
+      if (fuse_time) {
+        MVT_TRY(attn_block(tb, tok, M, MVT_ATTN_TIME, qkv, ld3, qkv + INNER, qkv + 2 * INNER, S, nx, 3, nullptr));
+      } else {
+        MVT_TRY(mvt_attention_bf16(qkv, ld3, S, 1, qkv + INNER, qkv + 2 * INNER, ld3, S, 1, att, INNER, n + NV, S, S, HEADS, DH_, BF, nullptr,
+                                   stream));
+        MVT_TRY(block(tb, tok, M, att, nx, 3, nullptr));
+      }
     }
     // ---- virtual <- point cross attention, per frame: group = frame (stride 1 row), items stride S rows
     unsigned short* qv = qkv + Mp * ld3;  // q|k|v rows of the virtual tokens
@@ -129,18 +143,27 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
       MVT_TRY(block(v2p, vt, Mv, av, &nx, 1, split_ws));
     }
     // ---- virtual self attention, per frame
-    MVT_TRY(mvt_attention_bf16(qv, ld3, 1, S, qv + INNER, qv + 2 * INNER, ld3, 1, S, av, INNER, S, NV, NV, HEADS, DH_, BF, nullptr, stream));
     {
       mvt_block_next nx[2] = {next_of(p2v.kv, qv + INNER, ld3, 0, 0, p2v.ctx_ln_w, p2v.ctx_ln_b, 1e-5f), {}};
       int nn = 1;
       if (!last) nx[nn++] = next_of(w->time_blk[i + 1].qkv, qkv_nx + Mp * ld3, ld3, 0, 0);  // virtual rows are final for this layer
-      MVT_TRY(block(vs, vt, Mv, av, nx, nn, split_ws));
+      if (fuse_vs) {
+        // (pass 1 reads the virtual q|k|v; the p2v k|v projection that overwrites k|v is written by pass 2, a later launch)
+        MVT_TRY(attn_block(vs, vt, Mv, MVT_ATTN_FRAME, qv, ld3, qv + INNER, qv + 2 * INNER, NV, nx, nn, split_ws));
+      } else {
+        MVT_TRY(mvt_attention_bf16(qv, ld3, 1, S, qv + INNER, qv + 2 * INNER, ld3, 1, S, av, INNER, S, NV, NV, HEADS, DH_, BF, nullptr, stream));
+        MVT_TRY(block(vs, vt, Mv, av, nx, nn, split_ws));
+      }
     }
     // ---- point <- virtual cross attention, per frame
-    MVT_TRY(mvt_attention_bf16(qp, INNER, 1, S, qv + INNER, qv + 2 * INNER, ld3, 1, S, att, INNER, S, n, NV, HEADS, DH_, BF, nullptr, stream));
     {
       const mvt_block_next nx = last ? mvt_block_next{} : next_of(w->time_blk[i + 1].qkv, qkv_nx, ld3, 0, 0);
-      MVT_TRY(block(p2v, tok, Mp, att, &nx, last ? 0 : 1, nullptr));
+      if (fuse_p2v && Mp >= 4096) {
+        MVT_TRY(attn_block(p2v, tok, Mp, MVT_ATTN_FRAME, qp, INNER, qv + INNER, qv + 2 * INNER, NV, &nx, last ? 0 : 1, nullptr));
+      } else {
+        MVT_TRY(mvt_attention_bf16(qp, INNER, 1, S, qv + INNER, qv + 2 * INNER, ld3, 1, S, att, INNER, S, n, NV, HEADS, DH_, BF, nullptr, stream));
+        MVT_TRY(block(p2v, tok, Mp, att, &nx, last ? 0 : 1, nullptr));
+      }
     }
     unsigned short* t_ = qkv; qkv = qkv_nx; qkv_nx = t_;
   }

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mvt_attention": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, P],
     "mvt_attention_bf16": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, I, P, P],
     "mvt_broadcast_rows": [P, P, I, I, I, I, P],
+    "mvt_attn_block_fused_bf16": [P, I, P, P, P, P, P, P, P, I, P, I, LL, I, P, P],
     "mvt_updateformer_workspace_bytes": [I, I],
     "mvt_updateformer_forward": [P, P, I, I, P, I, P, LL, P],
 }
@@ -432,7 +433,7 @@ COMPOSITE = True  # (the CPU host-logic tests, which replace the kernels one by 
 class UpdaterWeights(C.Structure):
     """mvt_updater_weights: host struct of device pointers (the tensors must outlive it: keep them referenced)."""
     _fields_ = [("depth", C.c_int), ("hidden", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int), ("n_virtual", C.c_int),
-                ("S", C.c_int), ("token_dim", C.c_int), ("out_dim", C.c_int), ("virtual_tokens", C.c_void_p),
+                ("S", C.c_int), ("token_dim", C.c_int), ("out_dim", C.c_int), ("fuse_attention", C.c_int), ("virtual_tokens", C.c_void_p),
                 ("input_transform", LinRows), ("flow0", LinRows), ("flow2", LinRows), ("flow4", LinRows),
                 ("time_blk", UpdaterBlock * UPDATER_MAX_DEPTH), ("v2p", UpdaterBlock * UPDATER_MAX_DEPTH),
                 ("vself", UpdaterBlock * UPDATER_MAX_DEPTH), ("p2v", UpdaterBlock * UPDATER_MAX_DEPTH)]
@@ -454,3 +455,24 @@ def updateformer_forward(weights: UpdaterWeights, x, ldx, n, delta, ldd, workspa
     """EfficientUpdateFormer.forward as one library call (bf16 mode, shipped geometry); workspace: uint8 device tensor."""
     _call("mvt_updateformer_forward", C.addressof(weights), _ptr(_f32c(x)), ldx, n, _ptr(delta), ldd, _ptr(workspace), workspace.numel(),
           _stream())
+
+
+ATTN_TIME, ATTN_FRAME = 1, 2
+
+
+class BlockAttn(C.Structure):
+    """mvt_block_attn."""
+    _fields_ = [("kind", C.c_int), ("S", C.c_int), ("n_keys", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int), ("ldq", C.c_int),
+                ("ldkv", C.c_int), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p)]
+
+
+def attn_block_fused_bf16(x, ldx, kind, S, q, ldq, k, v, ldkv, n_keys, wo, bo, w1, b1, w2, b2, H, nexts, M, Cc, ws=None):
+    """``block_fused_bf16`` with the preceding attention inside the kernel (bf16 q / k / v; 6 heads x 48)."""
+    assert q.dtype == k.dtype == v.dtype == torch.bfloat16
+    at = BlockAttn(kind, S, n_keys, 6, 48, ldq, ldkv, _ptr(q), _ptr(k), _ptr(v))
+    arr = (BlockNext * max(1, len(nexts)))()
+    for i, nx in enumerate(nexts):
+        arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],
+                           nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)), 1 if nx["y"].dtype == torch.bfloat16 else 0)
+    _call("mvt_attn_block_fused_bf16", _ptr(x), ldx, C.addressof(at), _ptr(wo), _ptr(bo), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), H,
+          C.cast(arr, C.c_void_p), len(nexts), M, Cc, _ptr(ws), _stream())

@@ -123,6 +123,8 @@ class MVTracker(nn.Module):
         self.bf16_tokens = os.environ.get("MVT_BF16_TOK", "1") != "0"  # bf16 mode: q/k/v and attention outputs stored as bf16
         self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
         self.bf16_store = os.environ.get("MVT_BF16_STORE", "1") != "0"  # bf16 mode: bf16 feature rows in the frame store
+        # attention inside the block kernels: bit 0 time, bit 1 point<-virtual, bit 2 virtual self (bit-identical to the separate launches)
+        self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "7"))
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
         d = self.updateformer_input_dim
@@ -211,7 +213,7 @@ class MVTracker(nn.Module):
     # ------------------------------------------------------------------ weight packing for the kernels
     def _signature(self, dev):
         assert self.precision in ("fp32", "bf16x3", "bf16"), self.precision
-        return (str(dev), self.precision) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        return (str(dev), self.precision, self.fuse_attention) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
     def _pack(self, dev) -> dict:
         sig = self._signature(dev)
@@ -296,6 +298,7 @@ class MVTracker(nn.Module):
         w = hip.UpdaterWeights()
         w.depth, w.hidden, w.heads, w.dim_head, w.n_virtual, w.S = self.depth, h, self.num_heads, self.dim_head, self.nv, self.S
         w.token_dim, w.out_dim = self.updateformer_input_dim, self.out_dim
+        w.fuse_attention = self.fuse_attention
         w.virtual_tokens = pk["virtual"].data_ptr()
         keep = []  # tensors referenced by the struct only
 

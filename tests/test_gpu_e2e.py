@@ -569,3 +569,25 @@ def test_updateformer_hidden_384_golden(golden, prec, tol):
     ref = g["out"]
     err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
     assert err < tol, err
+
+
+@pytest.mark.parametrize("n", [16, 1024, 37])
+def test_updater_fused_attention_bit_identical(model, n):
+    """Attention inside the block kernels (mvt_attn_block_fused_bf16: time / point<-virtual / virtual-self) performs the same
+    arithmetic in the same order as the separate attention launches: the updater output must be IDENTICAL, bit for bit, for
+    every combination -- n = 1024 is the C3 shape (tiles straddling the point / virtual boundary, 60-row track tiles),
+    n = 37 leaves partial tiles everywhere, n = 16 takes the small-M form of the point blocks."""
+    x = torch.randn(1, n, 12, 581, generator=torch.Generator().manual_seed(n)).to(DEV)
+    outs = {}
+    with _with_precision(model, "bf16"):
+        old = model.fuse_attention
+        try:
+            for f in (0, 1, 2, 4, 7):
+                model.fuse_attention = f
+                outs[f] = model.update_former(x).clone()
+            torch.cuda.synchronize()
+        finally:
+            model.fuse_attention = old
+    assert bool(torch.isfinite(outs[0]).all())
+    for f in (1, 2, 4, 7):
+        assert torch.equal(outs[f], outs[0]), f"fuse_attention={f}: max diff {(outs[f] - outs[0]).abs().max().item():.3e}"
