@@ -181,22 +181,48 @@ __device__ __forceinline__ void fill_wq(bf16x8 (&wq)[PFQ], const unsigned short*
 //   qrow(i) / krow(j): element row of query i / key j in q / k|v;  vt: this wave's V^T image [48][LDVA];  zrow: >= 40 zero
 //   elements (the d padding rows 48..63 of the second 32-row block);  arow0: tile row of query 0.
 constexpr int LDVA = 40, DHA = 48, VTA = DHA * LDVA;
+// operands of one wave_attention unit, as loaded from global memory (NMBQ query blocks, NKB key blocks)
+template <int NMBQ, int NKB> struct AttnFrags {
+  u32x4 q[NMBQ][3];   // lane (r, h) of block mb: Q[mb*32 + r][ks*16 + 8h .. +7]
+  u32x4 k[NKB][3];    // K[kb*32 + r][ks*16 + 8h .. +7]
+  u32x2 v[NKB][6];    // V[kb*32 + r][24h + 4i .. +3]
+};
 template <int NMBQ, int NKB, class QR, class KR>
-__device__ __forceinline__ void wave_attention(const unsigned short* __restrict__ q, int ldq, QR qrow, int nq,
-                                               const unsigned short* __restrict__ k, const unsigned short* __restrict__ v, int ldkv,
-                                               KR krow, int nk, int hd, unsigned short* vt, const unsigned short* zrow,
-                                               unsigned short* As, int lda, int arow0, int lane) {
+__device__ __forceinline__ void attn_load(AttnFrags<NMBQ, NKB>& f, const unsigned short* __restrict__ q, int ldq, QR qrow, int nq,
+                                          const unsigned short* __restrict__ k, const unsigned short* __restrict__ v, int ldkv, KR krow,
+                                          int nk, int hd, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const float scale = 1.0f / sqrtf((float)DHA);
-  bf16x8 qf[NMBQ][3];
 #pragma unroll
   for (int mb = 0; mb < NMBQ; ++mb) {
     const int qi = mb * 32 + r;
     const long long qo = qrow(qi < nq ? qi : nq - 1) * (long long)ldq + hd * DHA;
 #pragma unroll
+    for (int ks = 0; ks < 3; ++ks) f.q[mb][ks] = *reinterpret_cast<const u32x4*>(q + qo + ks * 16 + 8 * h);
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int key = kb * 32 + r;
+    const long long ko = krow(key < nk ? key : nk - 1) * (long long)ldkv + hd * DHA;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) f.k[kb][ks] = *reinterpret_cast<const u32x4*>(k + ko + ks * 16 + 8 * h);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f.v[kb][i] = *reinterpret_cast<const u32x2*>(v + ko + 24 * h + 4 * i);
+  }
+}
+__device__ __forceinline__ f32x4 bf4_to_f32(unsigned lo, unsigned hi) {
+  return (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xFFFF0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
+}
+template <int NMBQ, int NKB>
+__device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int nq, int nk, int hd, unsigned short* vt,
+                                             const unsigned short* zrow, unsigned short* As, int lda, int arow0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float scale = 1.0f / sqrtf((float)DHA);
+  bf16x8 qf[NMBQ][3];
+#pragma unroll
+  for (int mb = 0; mb < NMBQ; ++mb) {
+#pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
-      f32x4 a = load_act4(reinterpret_cast<const float*>(q), qo + ks * 16 + 8 * h, 1);
-      f32x4 b = load_act4(reinterpret_cast<const float*>(q), qo + ks * 16 + 8 * h + 4, 1);
+      f32x4 a = bf4_to_f32(f.q[mb][ks][0], f.q[mb][ks][1]), b = bf4_to_f32(f.q[mb][ks][2], f.q[mb][ks][3]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         a[e] *= scale;
@@ -224,16 +250,14 @@ __device__ __forceinline__ void wave_attention(const unsigned short* __restrict_
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     const int key = kb * 32 + r;
-    const long long ko = krow(key < nk ? key : nk - 1) * (long long)ldkv + hd * DHA;
     bf16x8 kf[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) kf[ks] = ldg_frag(k + ko + ks * 16 + 8 * h);
+    for (int ks = 0; ks < 3; ++ks) kf[ks] = __builtin_bit_cast(bf16x8, f.k[kb][ks]);
     {
-      const long long vo = ko + 24 * h;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        u32x2 w = *reinterpret_cast<const u32x2*>(v + vo + 4 * i);
+        u32x2 w = f.v[kb][i];
         if (key >= nk) w = (u32x2){0u, 0u};
 #pragma unroll
         for (int e = 0; e < 4; ++e) vt[(24 * h + 4 * i + e) * LDVA + r] = (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xFFFFu));
@@ -429,20 +453,38 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     static_assert(XW + (2 * BM * LDH - BM * LDA - 8) / VTA >= 6, "six V^T images fit beside the attention tile");
     __syncthreads();
     if (ATT == 1) {
+      // units (track, head) are dealt round-robin to the waves; the operands of ALL of a wave's units are fetched first (one
+      // exposed memory latency instead of one per unit), then the units are computed back to back
       const int ntr = bmv / p.S;
-      for (int u = wave; u < ntr * 6; u += 8) {
-        const int tr = u / 6, hd = u - tr * 6;
-        const long long mt = m0 + (long long)tr * p.S;  // first row of the track
-        if (mt >= p.M) continue;
-        auto row = [&](int i) { return mt + i; };
-        wave_attention<1, 1>(p.aq, p.ldaq, row, p.S, p.ak, p.av, p.ldakv, row, p.S, hd, vt, zrow, As, LDA, tr * p.S, lane);
+      constexpr int MAXU = 4;  // ceil(5 tracks x 6 heads / 8 waves); more tracks per tile (S < 12) loop over groups of MAXU
+      for (int u0 = wave; u0 < ntr * 6; u0 += 8 * MAXU) {
+        AttnFrags<1, 1> fr[MAXU];
+        bool ok[MAXU];
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+          const int u = u0 + 8 * i;
+          const int tr = u / 6, hd = u - tr * 6;
+          long long mt = m0 + (long long)tr * p.S;  // first row of the track
+          ok[i] = u < ntr * 6 && mt < p.M;
+          if (!ok[i]) mt = m0;  // (a valid address; the fragments are not used)
+          auto row = [&](int j) { return mt + j; };
+          attn_load<1, 1>(fr[i], p.aq, p.ldaq, row, p.S, p.ak, p.av, p.ldakv, row, p.S, ok[i] ? hd : 0, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+          const int u = u0 + 8 * i;
+          const int tr = u / 6, hd = u - tr * 6;
+          if (ok[i]) attn_compute<1, 1>(fr[i], p.S, p.S, hd, vt, zrow, As, LDA, tr * p.S, lane);
+        }
       }
     } else if (wave < 6 && grow(0) >= 0) {
       const long long left = ntok - (long long)blockIdx.x * BM;
       const int nq = left < BM ? (int)left : BM;
       auto qrow = [&](int i) { return ((long long)blockIdx.x * BM + i) * p.S + (long long)blockIdx.z; };
       auto krow = [&](int j) { return (long long)j * p.S + (long long)blockIdx.z; };
-      wave_attention<NMB, 2>(p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, vt, zrow, As, LDA, 0, lane);
+      AttnFrags<NMB, 2> fr;
+      attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, lane);
+      attn_compute<NMB, 2>(fr, nq, p.nkeys, wave, vt, zrow, As, LDA, 0, lane);
     }
     __syncthreads();
     gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);

@@ -171,3 +171,30 @@ if "block" in which:
                 t_s = timeit(lambda: hip.block_fused_bf16(x, C, att, Ko, Ko, who, Ko, bo, wh1, C, b1, wh2, H, b2, H, nexts, M, C, ws=ws))
                 extra = f"   split path: {t_s:.1f} us"
             print(f"block_fused M={M} nexts={Ns}: {t_f:.1f} us   (MLP only: {t_n:.1f} us){extra}")
+
+if "window" in which:
+    # Secondary operator a7' (CorrBlock.corr_sample, spatracker/blocks.py:492-533) at its C3 shape: S=12 frames, N=1024 tracks,
+    # C=128, 128x128 maps, 4 levels, r=4.  Algorithmic bytes per (frame, track, level) unit:
+    # (2r+2)^2 texels x C x 4 B + target C x 4 B + coord 8 B read, (2r+1)^2 x 4 B written = 52 044 B.
+    S, N, C, Hm, r, L = 12, 1024, 128, 128, 4, 4
+    D = (2 * r + 1) ** 2
+    unit = (2 * r + 2) ** 2 * C * 4 + C * 4 + 8 + D * 4
+    maps = []
+    f = torch.randn(S, Hm, Hm, C, device=dev)
+    for lvl in range(L):
+        maps.append(f.contiguous())
+        f = torch.nn.functional.avg_pool2d(f.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    tg = torch.randn(S, N, C, device=dev)
+    cd = torch.rand(S, N, 2, device=dev) * (Hm - 1)
+    out = torch.zeros(S, N, L * D, device=dev)
+
+    def run(levels=range(L)):
+        for lvl in levels:
+            h = maps[lvl].shape[1]
+            hip.window_corr(maps[lvl], tg, cd, out, S, N, C, h, h, lvl, r, L * D, lvl * D)
+
+    tot = timeit(run)
+    per = [timeit(lambda l=l: run([l])) for l in range(L)]
+    alg = S * N * unit
+    print(f"window_corr C3 shape: 4 levels {tot:.1f} us = {L * alg / tot / 1e3:.0f} GB/s algorithmic ({L * alg / tot / 1e3 / 8000:.2f} of 8 TB/s); per level "
+          + ", ".join(f"L{l} {t:.1f} us ({alg / t / 1e3:.0f} GB/s)" for l, t in enumerate(per)) + f"; {unit} B/unit, {alg / 1e6:.0f} MB per level launch")
