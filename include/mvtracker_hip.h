@@ -352,6 +352,18 @@ int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, c
 /* x[(n*S+s)*ld + 0:C] = v[n][0:C] for all s  (virtual-token broadcast, blocks.py:458-459). */
 int mvt_broadcast_rows(const float* v, float* x, int ld, int n, int S, int C, void* stream);
 
+/* Track state of one sliding window (mvtracker.py:505-511, 645-655, 695): n tracks (sorted by query frame), the first p0 of
+ * them carried over from the previous window (prev_coords [p0][S][3], prev_vis [p0][S] logits; window stride S/2).
+ * qxyz [n][3], qt [n] int32 query frames, feat_init [n][C].  Writes coords [n][S][3], mask_vis [n][S][2] = (track mask,
+ * initial visibility), ffeats [n][S][C].  Window slot s reads frame min(w + s, T - 1). */
+int mvt_window_prepare(const float* qxyz, const int* qt, const float* feat_init, const float* prev_coords, const float* prev_vis,
+                       int n, int p0, int S, int C, int w, int T, float* coords, float* mask_vis, float* ffeats, void* stream);
+/* Results of the window into the clip outputs in the caller's query order (mvtracker.py:692-693, 710-711): for s < min(S, T - w)
+ * traj[(w+s)][order[i]] = coords[i][s], vis_logit = vis[i][s], vis_prob = sigmoid(vis[i][s]).  traj [T][N][3], vis_* [T][N],
+ * order [n] int64. */
+int mvt_window_store(const float* coords, const float* vis, const long long* order, int n, int S, int w, int T, int N, float* traj,
+                     float* vis_logit, float* vis_prob, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Composite entry points: one C call per stage of the hot path instead of one per kernel, so that a
  * non-Python caller can run the updater as ONE operation and the launch order lives in the library, not in host glue.

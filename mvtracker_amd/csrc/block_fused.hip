@@ -433,6 +433,23 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   if (MODE != 2)
     for (int i = t; i < p.H; i += NT) b1s[i] = p.b1[i];
   const long long MC = p.M * (long long)C;
+  // a projection runs in this workgroup when its row range meets the workgroup's rows (workgroup-uniform)
+  auto active = [&](int q) { return q < p.n_next && rlo < p.next[q].row_hi && rhi > p.next[q].row_lo; };
+  bf16x8 wq[PFQ];  // the weight-fragment queue, chained through the MLP and the follow-up projections
+  // 32-row tiles (the 768 virtual-token rows, pure latency chains) have registers to spare: the first 16 weight fragments the
+  // wave will consume are requested HERE, so their memory round trip (the ~40 MB of updater weights do not live in L2) overlaps
+  // the token / attention-operand loads and the LayerNorm instead of following them.
+  constexpr bool EARLY = NMB == 1 && MODE != 0;
+  bool early_have = false;
+  if (EARLY && MODE == 1) {
+    fill_wq(wq, p.w1 + ((long long)(wave % K_::JW) * (C / 16) * 64 + lane) * 8 + (long long)blockIdx.y * K_::JW * (C / 16) * FS);
+  } else if (EARLY && MODE == 2) {
+    const int nb0e = (int)blockIdx.y * 8 + wave;
+    if (active(0) && nb0e < (p.next[0].N + 31) / 32) {
+      fill_wq(wq, p.next[0].w + ((long long)nb0e * (C / 16) * 64 + lane) * 8);
+      early_have = true;
+    }
+  }
 
   // token values of this wave's 32-channel slice: v[mb][e] = x[m0 + mb*32 + r][wave*32 + (e&3) + 8*(e>>2) + 4h]
   f32x16 v[NMB];
@@ -561,9 +578,6 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     }
   };
   if (MODE != 2) ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
-  bf16x8 wq[PFQ];  // the weight-fragment queue, chained through the MLP and the follow-up projections
-  // a projection runs in this workgroup when its row range meets the workgroup's rows (workgroup-uniform)
-  auto active = [&](int q) { return q < p.n_next && rlo < p.next[q].row_hi && rhi > p.next[q].row_lo; };
   const bool tail_next = MODE == 0 && active(0) && wave < (p.next[0].N + 31) / 32;
   if (MODE != 2) {
     f32x16 acc2[NMB];
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     // k-steps each, so the queue always holds the next 16 fragments of that sequence (>= 16 MFMA k-steps of lookahead,
     // which is what an L2 round trip needs; two half-depth queues left every fragment ~250 cycles short)
     const int c_lo = MODE == 1 ? (int)blockIdx.y : 0, c_hi = MODE == 1 ? c_lo + 1 : nchunk;
-    fill_wq(wq, w1row + (long long)c_lo * JW * (C / 16) * FS);
+    if (!(EARLY && MODE == 1)) fill_wq(wq, w1row + (long long)c_lo * JW * (C / 16) * FS);
 #pragma unroll 1
     for (int c = c_lo; c < c_hi; ++c) {
       unsigned short* Hb = Hs[c & 1];
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   if (MODE == 0 || (p.ws && blockIdx.y == 0)) store_x();  // (never in the projection-only form: x is read-only there)
 
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
-  bool have = tail_next;  // the queue already holds this wave's first block of the projection
+  bool have = tail_next || early_have;  // the queue already holds this wave's first block of the projection
 #pragma unroll
   for (int q = 0; q < MVT_BLOCK_MAX_NEXT; ++q) {  // static indices: a dynamically indexed kernel-argument array would live in scratch
     if (q >= p.n_next) break;

@@ -49,6 +49,67 @@ __global__ __launch_bounds__(256) void token_assemble_kernel(const float* __rest
     }
     x[row * ldx + d] = (v + pos[(long long)n * D + d]) + time_embed[(long long)s * D + d];
   }
+  // the pad columns [D, ldx) are read as K padding by the input-transform GEMM: exact zeros, written here (no memset of x)
+  if (threadIdx.x < ldx - D) x[row * ldx + D + threadIdx.x] = 0.f;
+}
+
+// Per-window track state (mvtracker.py:510-511, 645-680): one launch instead of a dozen tensor ops.
+//   coords [n][S][3]: tracks carried over from the previous window (n < p0) continue from its second half, the last estimate
+//                     held (:648-651); new tracks start at their query point (:510)
+//   mask_vis [n][S][2]: (track_mask, vis_init): the mask is (frame >= query frame) minus what earlier windows already covered
+//                     (:505-507, :695), window slots past the clip repeat the last frame (:598-604); vis_init is the previous
+//                     window's LOGIT for carried tracks (:653-655), 10 for new ones (:511)
+//   ffeats [n][S][C]: the track's initial feature repeated over the window (:645)
+__global__ void window_prepare_kernel(const float* __restrict__ qxyz, const int* __restrict__ qt, const float* __restrict__ feat_init,
+                                      const float* __restrict__ prev_coords, const float* __restrict__ prev_vis, int n, int p0, int S,
+                                      int C, int w, int T, float* __restrict__ coords, float* __restrict__ mask_vis,
+                                      float* __restrict__ ffeats) {
+  const long long total = (long long)n * S * (C / 4);
+  const int half = S / 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % (C / 4));
+    const long long row = i / (C / 4);  // tr * S + s
+    const int s = (int)(row % S);
+    const int tr = (int)(row / S);
+    *reinterpret_cast<f32x4*>(ffeats + row * C + cq * 4) = *reinterpret_cast<const f32x4*>(feat_init + (long long)tr * C + cq * 4);
+    if (cq == 0) {
+      const int sp = s < half ? half + s : S - 1;  // slot of the previous window this one continues from
+      float vis = 10.0f;
+      if (tr < p0) {
+        vis = prev_vis[(long long)tr * S + sp];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) coords[row * 3 + a] = prev_coords[((long long)tr * S + sp) * 3 + a];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) coords[row * 3 + a] = qxyz[(long long)tr * 3 + a];
+      }
+      const int S_local = T - w < S ? T - w : S;
+      const int f = w + (s < S_local ? s : S_local - 1);
+      const bool on = f >= qt[tr] && !(tr < p0 && f < w + half);
+      mask_vis[row * 2] = on ? 1.0f : 0.0f;
+      mask_vis[row * 2 + 1] = vis;
+    }
+  }
+}
+
+// Results of one window into the clip-level outputs, in the caller's (unsorted) query order (mvtracker.py:692-693, 710-711):
+// traj [T][N][3], vis_logit / vis_prob [T][N]; order[tr] = position of sorted track tr in the caller's query list.
+__global__ void window_store_kernel(const float* __restrict__ coords, const float* __restrict__ vis, const long long* __restrict__ order,
+                                    int n, int S, int w, int T, int N, float* __restrict__ traj, float* __restrict__ vis_logit,
+                                    float* __restrict__ vis_prob) {
+  const int S_local = T - w < S ? T - w : S;
+  const long long total = (long long)n * S_local;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)(i % S_local);
+    const int tr = (int)(i / S_local);
+    const long long src = (long long)tr * S + s;
+    const long long dst = (long long)(w + s) * N + order[tr];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) traj[dst * 3 + a] = coords[src * 3 + a];
+    const float lg = vis[src];
+    vis_logit[dst] = lg;
+    vis_prob[dst] = 1.0f / (1.0f + expf(-lg));
+  }
 }
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
@@ -162,6 +223,24 @@ extern "C" int mvt_token_assemble(const float* coords, const float* fcorr, int F
   MVT_REQUIRE(Fc > 0 && C > 0 && ldx >= 3 * E + 3 + Fc + C + 2);
   hipLaunchKernelGGL(token_assemble_kernel, dim3((unsigned)((long long)N * S)), dim3(256), 0, mvt_stream(stream), coords, fcorr, Fc,
                      ffeats, C, mask_vis, pos, time_embed, N, S, E, x, ldx);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_window_prepare(const float* qxyz, const int* qt, const float* feat_init, const float* prev_coords,
+                                  const float* prev_vis, int n, int p0, int S, int C, int w, int T, float* coords, float* mask_vis,
+                                  float* ffeats, void* stream) {
+  MVT_REQUIRE(qxyz && qt && feat_init && coords && mask_vis && ffeats && n > 0 && p0 >= 0 && p0 <= n && S >= 2 && C > 0 && C % 4 == 0);
+  MVT_REQUIRE(w >= 0 && w < T && (p0 == 0 || (prev_coords && prev_vis)));
+  hipLaunchKernelGGL(window_prepare_kernel, dim3(grid_for((long long)n * S * (C / 4))), dim3(256), 0, mvt_stream(stream), qxyz, qt,
+                     feat_init, prev_coords, prev_vis, n, p0, S, C, w, T, coords, mask_vis, ffeats);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_window_store(const float* coords, const float* vis, const long long* order, int n, int S, int w, int T, int N,
+                                float* traj, float* vis_logit, float* vis_prob, void* stream) {
+  MVT_REQUIRE(coords && vis && order && traj && vis_logit && vis_prob && n > 0 && n <= N && S > 0 && w >= 0 && w < T);
+  hipLaunchKernelGGL(window_store_kernel, dim3(grid_for((long long)n * S)), dim3(256), 0, mvt_stream(stream), coords, vis, order, n, S, w, T,
+                     N, traj, vis_logit, vis_prob);
   return mvt_launch_status();
 }
 

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mvt_attention_bf16": [P, I, LL, LL, P, P, I, LL, LL, P, I, I, I, I, I, I, I, P, P],
     "mvt_broadcast_rows": [P, P, I, I, I, I, P],
     "mvt_attn_block_fused_bf16": [P, I, P, P, P, P, P, P, P, I, P, I, LL, I, P, P],
+    "mvt_window_prepare": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P],
+    "mvt_window_store": [P, P, P, I, I, I, I, I, P, P, P, P],
     "mvt_updateformer_workspace_bytes": [I, I],
     "mvt_updateformer_forward": [P, P, I, I, P, I, P, LL, P],
 }
@@ -403,6 +405,17 @@ def attention_bf16(q, ldq, q_gs, q_is, k, v, ldkv, k_gs, k_is, o, ldo, groups, n
     assert ws is None or (ws.dtype == torch.float32 and ws.numel() >= attention_ws_floats(groups, nq, heads))
     _call("mvt_attention_bf16", _ptr(q), ldq, q_gs, q_is, _ptr(k), _ptr(v), ldkv, k_gs, k_is, _ptr(o), ldo, groups, nq, nk, heads,
           dh, _io(q, o), _ptr(ws), _stream())
+
+
+def window_prepare(qxyz, qt, feat_init, prev_coords, prev_vis, n, p0, S, Cc, w, T, coords, mask_vis, ffeats):
+    assert qt.dtype == torch.int32
+    _call("mvt_window_prepare", _ptr(_f32c(qxyz)), _ptr(qt), _ptr(_f32c(feat_init)), _ptr(prev_coords), _ptr(prev_vis), n, p0, S, Cc, w, T,
+          _ptr(coords), _ptr(mask_vis), _ptr(ffeats), _stream())
+
+
+def window_store(coords, vis, order, n, S, w, T, N, traj, vis_logit, vis_prob):
+    assert order.dtype == torch.int64
+    _call("mvt_window_store", _ptr(coords), _ptr(vis), _ptr(order), n, S, w, T, N, _ptr(traj), _ptr(vis_logit), _ptr(vis_prob), _stream())
 
 
 def broadcast_rows(v, x, ld, n, S, Cc):

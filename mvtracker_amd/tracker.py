@@ -719,11 +719,18 @@ class MVTracker(nn.Module):
     # ------------------------------------------------------------------ one window (mvtracker.py:244-410)
     @hip.guarded
     def refine_window(self, store, frame0, coords, vis_init, track_mask, feat_init, iters=4, nan_flag=None, trace=None):
-        """Iterative refinement of one window.
+        """Iterative refinement of one window (test / parity entry; ``forward`` prepares the same state with one kernel).
 
-        coords (n,S,3) world xyz (updated in place and returned per iteration), vis_init (n,S) logits,
-        track_mask (n,S) {0,1}, feat_init (n,S,C).  Window slot s reads frame min(frame0+s, T-1).
-        Returns (list of coords per iteration, vis logits (n,S))."""
+        coords (n,S,3) world xyz, vis_init (n,S) logits, track_mask (n,S) {0,1}, feat_init (n,S,C).  Window slot s reads
+        frame min(frame0+s, T-1).  Returns (list of coords per iteration, vis logits (n,S))."""
+        coords = coords.contiguous().clone()
+        ffeats = feat_init.contiguous().clone()
+        mask_vis = torch.stack([track_mask.float(), vis_init.float()], dim=2).contiguous()
+        return self._refine(store, frame0, coords, ffeats, mask_vis, iters, nan_flag, trace)
+
+    def _refine(self, store, frame0, coords, ffeats, mask_vis, iters=4, nan_flag=None, trace=None):
+        """The refinement loop (mvtracker.py:350-408) on prepared state: coords (n,S,3) and ffeats (n,S,C) are updated IN PLACE,
+        mask_vis (n,S,2) = (track mask, initial visibility logit).  Returns ([coords per traced iteration ..., final], vis)."""
         S, C, K, L, E = self.S, self.latent_dim, self.corr_neighbors, self.corr_n_levels, self.flow_embed_dim
         n = coords.shape[0]
         dev = coords.device
@@ -731,16 +738,13 @@ class MVTracker(nn.Module):
         D = self.updateformer_input_dim
         T = store["T"]
         Fc = L * K * 4
-        coords = coords.contiguous().clone()
-        ffeats = feat_init.contiguous().clone()
-        mask_vis = torch.stack([track_mask.float(), vis_init.float()], dim=2).contiguous()
         pos = torch.empty(n, D, device=dev)
         hip.pos_embed(coords, n, S, D, _round_up(D, 6), pos)
         fcorr = torch.empty(n, S, Fc, device=dev)
         ldx = _round_up(D, 4)
-        x = torch.zeros(n * S, ldx, device=dev)
+        x = torch.empty(n * S, ldx, device=dev)      # (token_assemble writes the pad columns as zeros)
         ldd = _round_up(self.out_dim, 4)
-        delta = torch.zeros(n * S, ldd, device=dev)
+        delta = torch.empty(n * S, ldd, device=dev)  # (out_dim columns are written and read; the pad column is never read)
         dn = torch.empty(n * S, C, device=dev)
         nsegs = [self._nseg(store["P"][lvl], K) for lvl in range(L)]
         keys = [torch.empty(n * S * nsegs[lvl] * K, device=dev, dtype=torch.int64) for lvl in range(L)]
@@ -775,8 +779,10 @@ class MVTracker(nn.Module):
                 trace.setdefault("delta", []).append(delta[:, :self.out_dim].reshape(n, S, -1).clone())
             hip.delta_split(delta, ldd, *pk["ffeats_norm"], coords, dn, n * S, C, nan_flag)
             self._lin(pk, "ffeats_updater.0", dn, C, n * S, ffeats, C, hip.ACT_GELU_ERF, R=ffeats, ldr=C)
-            if trace is not None or it + 1 == iters:  # (the intermediate estimates only feed the training loss upstream)
+            if trace is not None:  # (the intermediate estimates only feed the training loss upstream)
                 preds.append(coords.clone())
+        if trace is None:
+            preds.append(coords)
         vis = torch.empty(n, S, device=dev)
         hip.rowdot(ffeats, C, *pk["vis"], vis, n * S, C)
         if trace is not None:
@@ -828,21 +834,16 @@ class MVTracker(nn.Module):
         qt_dev = query_points[:, 0].long()
         qt = qt_dev.cpu().numpy()
         order = np.argsort(qt, kind="stable")  # mvtracker.py:514 (order among equal t is unobservable)
-        inv_order = np.argsort(order, kind="stable")
         qt_s = qt[order]
         order_d = torch.from_numpy(order).to(dev)
-        inv_d = torch.from_numpy(inv_order).to(dev)
         qxyz = query_points[order_d, 1:].contiguous()  # (N,3), sorted by start frame
 
-        traj = torch.zeros(T, N, 3, device=dev)
+        traj = torch.zeros(T, N, 3, device=dev)       # clip outputs in the caller's query order (window_store un-sorts)
         vis_prob = torch.zeros(T, N, device=dev)
         vis_logit = torch.zeros(T, N, device=dev)
         feat_init = torch.zeros(N, C, device=dev)
         nan_flag = torch.zeros(1, device=dev, dtype=torch.int32)
-        frames = torch.arange(T, device=dev)
-        track_mask = (frames[:, None] >= qt_dev[order_d][None, :])  # (T,N) bool, mvtracker.py:505-507
-        coords_init = qxyz[:, None, :].repeat(1, S, 1)  # (N,S,3), mvtracker.py:510
-        vis_init = torch.full((N, S), 10.0, device=dev)  # mvtracker.py:511
+        qt_sd = torch.from_numpy(qt_s.astype(np.int32)).to(dev)
 
         w = int(qt_s.min())
         windows = []
@@ -875,7 +876,6 @@ class MVTracker(nn.Module):
             assert p1 > 0
             while pending and pending[0][0] < w + S:  # the frames this window reads must have left the encoder
                 torch.cuda.current_stream(dev).wait_event(pending.pop(0)[1])
-            S_local = min(S, T - w)
             if p1 > p0:  # feature init: 1-NN in the fused level-0 cloud of the query frame (:607-645)
                 P0 = store["P"][0]
                 ns = self._nseg(P0, 1)
@@ -889,38 +889,31 @@ class MVTracker(nn.Module):
                                  grid=store["tile_grid"][0])
                     hip.knn1_gather(store["fvec"][0], P0, C, keys, b - a, ns, t, feat_init[a:b])
                     a = b
-            if p0 > 0:  # carry-over from the previous window (:648-655); vis is the previous LOGIT
-                last_c = coords[-1][:p0, S // 2:]
-                coords_init[:p0, :S // 2] = last_c
-                coords_init[:p0, S // 2:] = last_c[:, -1:].expand(-1, S - S // 2, -1)
-                last_v = vis[:p0, S // 2:]
-                vis_init[:p0, :S // 2] = last_v
-                vis_init[:p0, S // 2:] = last_v[:, -1:].expand(-1, S - S // 2)
-            tm = track_mask[w:w + S, :p1]
-            if S_local < S:
-                tm = torch.cat([tm, tm[-1:].expand(S - S_local, -1)], 0)
+            # window state in one launch: carry-over of coords / visibility LOGITS from the previous window (:648-655), track mask
+            # (:505-507, :695; the repeat-last-frame padding of :598-604 is a clamped frame index), features repeated over S (:645)
+            wc = torch.empty(p1, S, 3, device=dev)
+            wf = torch.empty(p1, S, C, device=dev)
+            wm = torch.empty(p1, S, 2, device=dev)
+            hip.window_prepare(qxyz, qt_sd, feat_init, coords, vis, p1, p0, S, C, w, T, wc, wm, wf)
             wtrace = None
             if trace is not None:
                 wtrace = {}
                 trace.append(wtrace)
-            coords, vis = self.refine_window(store, w, coords_init[:p1], vis_init[:p1], tm.t(), feat_init[:p1, None, :].expand(-1, S, -1),
-                                             iters=iters, nan_flag=nan_flag, trace=wtrace)
-            traj[w:w + S, :p1] = coords[-1][:, :S_local].permute(1, 0, 2)  # :692-693
-            vis_logit[w:w + S, :p1] = vis[:, :S_local].t()
-            vis_prob[w:w + S, :p1] = torch.sigmoid(vis[:, :S_local].t())
-            track_mask[:w + S, :p1] = False  # :695
+            preds, vis = self._refine(store, w, wc, wf, wm, iters=iters, nan_flag=nan_flag, trace=wtrace)
+            coords = preds[-1]
+            hip.window_store(coords, vis, order_d, p1, S, w, T, N, traj, vis_logit, vis_prob)  # :692-693, un-sorted (:710-711)
             windows.append((w, p1))
             w += S // 2
             p0 = p1
         for _, ev in pending:  # frames no window consumed: still join the side stream before the inputs are released
             torch.cuda.current_stream(dev).wait_event(ev)
         self.last_windows = windows
-        self.last_vis_logits = vis_logit[:, inv_d][None]
+        self.last_vis_logits = vis_logit[None]
         self.last_nan_flag = nan_flag
         results = {
-            "traj_e": traj[:, inv_d][None],
+            "traj_e": traj[None],
             "feat_init": feat_init[None, None].expand(1, S, -1, -1),
-            "vis_e": vis_prob[:, inv_d][None],
+            "vis_e": vis_prob[None],
         }
         return results
 

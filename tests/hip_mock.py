@@ -361,6 +361,8 @@ def token_assemble(coords, fcorr, Fc, ffeats, Cc, mask_vis, pos, time_embed, N, 
     t = torch.cat(parts + [fl, fcorr.reshape(N, S, Fc), ffeats.reshape(N, S, Cc), mask_vis.reshape(N, S, 2)], 2)
     t = t + pos.reshape(N, 1, D) + time_embed.reshape(1, S, D)
     torch.as_strided(x, (N * S, D), (ldx, 1)).copy_(t.reshape(N * S, D))
+    if ldx > D:
+        torch.as_strided(x, (N * S, ldx - D), (ldx, 1), x.storage_offset() + D).zero_()
 
 
 def delta_split(delta, ldd, gw, gb, coords, dn, rows, Cc, nan_flag=None):
@@ -404,6 +406,33 @@ def window_corr(fmap, targets, coords, out, BS, N, Cc, h, w, level, radius, ldo,
     raise NotImplementedError("window_corr is only exercised on the GPU")
 
 
+def window_prepare(qxyz, qt, feat_init, prev_coords, prev_vis, n, p0, S, Cc, w, T, coords, mask_vis, ffeats):
+    half = S // 2
+    ffeats.reshape(n, S, Cc).copy_(feat_init.reshape(-1, Cc)[:n, None, :].expand(n, S, Cc))
+    c = coords.reshape(n, S, 3)
+    c.copy_(qxyz.reshape(-1, 3)[:n, None, :].expand(n, S, 3))
+    vis = torch.full((n, S), 10.0)
+    if p0 > 0:
+        sp = [half + s_ if s_ < half else S - 1 for s_ in range(S)]
+        c[:p0] = prev_coords.reshape(-1, S, 3)[:p0][:, sp]
+        vis[:p0] = prev_vis.reshape(-1, S)[:p0][:, sp]
+    s_local = min(S, T - w)
+    f = torch.tensor([w + min(s_, s_local - 1) for s_ in range(S)])
+    on = f[None, :] >= qt.reshape(-1)[:n, None]
+    on[:p0] &= ~(f[None, :] < w + half)
+    mv = mask_vis.reshape(n, S, 2)
+    mv[..., 0] = on.float()
+    mv[..., 1] = vis
+
+
+def window_store(coords, vis, order, n, S, w, T, N, traj, vis_logit, vis_prob):
+    s_local = min(S, T - w)
+    o = order.reshape(-1)[:n]
+    traj.reshape(T, N, 3)[w:w + s_local, o] = coords.reshape(n, S, 3)[:, :s_local].permute(1, 0, 2)
+    vis_logit.reshape(T, N)[w:w + s_local, o] = vis.reshape(n, S)[:, :s_local].t()
+    vis_prob.reshape(T, N)[w:w + s_local, o] = torch.sigmoid(vis.reshape(n, S)[:, :s_local].t())
+
+
 def require_device(t):
     return None
 
@@ -415,6 +444,6 @@ def install(monkeypatch):
     me = sys.modules[__name__]
     for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 ln_proj_bf16 mlp_fused_bf16 rgb_to_nhwc4 rgb_images_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
                  "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
-                 "rowdot layernorm attention attention_bf16 broadcast_rows window_corr require_device").split():
+                 "rowdot layernorm attention attention_bf16 broadcast_rows window_corr window_prepare window_store require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))
     monkeypatch.setattr(hip, "COMPOSITE", False)  # the per-kernel sequencing is what these tests exercise
