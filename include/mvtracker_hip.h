@@ -349,6 +349,10 @@ int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, c
                        float* workspace /* NULL, or 4 * groups*heads*ceil(nq/64) * 4352 floats: lets a long-key attention
                                            with few (group, head) chunks cut its keys over 4 workgroups per chunk */,
                        void* stream);
+/* io_flags bit of mvt_attention_bf16: the key-split partials are combined by the LAST workgroup of every chunk to publish its
+ * partial (fixed combination order: deterministic) instead of by a second launch.  The workspace then carries a tail of
+ * groups*heads*ceil(nq/64) uint32 ticket counters after the partials; they must be ZERO on entry and are left zero. */
+#define MVT_ATTN_FUSED_MERGE 4
 /* x[(n*S+s)*ld + 0:C] = v[n][0:C] for all s  (virtual-token broadcast, blocks.py:458-459). */
 int mvt_broadcast_rows(const float* v, float* x, int ld, int n, int S, int C, void* stream);
 
@@ -400,14 +404,30 @@ typedef struct mvt_updater_block {
 typedef struct mvt_updater_weights {
   int depth, hidden, heads, dim_head, n_virtual, S, token_dim, out_dim;
   int fuse_attention; /* bit 0: time attention, bit 1: point<-virtual, bit 2: virtual self attention run inside the block kernels
-                         (mvt_attn_block_fused_bf16) instead of as separate launches; results are bit-identical either way */
+                         (mvt_attn_block_fused_bf16) instead of as separate launches; bit 3: the key-split virtual<-point attention
+                         merges its partials itself (MVT_ATTN_FUSED_MERGE); results are bit-identical either way */
   const float* virtual_tokens; /* [n_virtual][hidden] */
   mvt_lin_rows input_transform, flow0, flow2, flow4;
   mvt_updater_block time_blk[MVT_UPDATER_MAX_DEPTH], v2p[MVT_UPDATER_MAX_DEPTH], vself[MVT_UPDATER_MAX_DEPTH], p2v[MVT_UPDATER_MAX_DEPTH];
+  /* optional, for the fused track update of mvt_updateformer_forward (NULL w = not available): the flow head once more as
+   * fragment-major bf16 (K of flow2 / flow4 padded to 144) and the feature updater of mvtracker.py:178-179, 393-399 */
+  mvt_lin_frag flow0_frag, flow2_frag, flow4_frag, ffeats_updater;
+  const float* ffeats_norm_w; /* GroupNorm(1, 128) affine */
+  const float* ffeats_norm_b;
 } mvt_updater_weights;
 long long mvt_updateformer_workspace_bytes(int n, int S); /* host; -1 on bad arguments */
+/* delta may be NULL when the track update is fused: with coords != NULL ([n*S][3]) and ffeats ([n*S][128]) the call also applies
+ * coords += delta[:, 0:3], ffeats += gelu(Linear(GroupNorm(delta[:, 3:]))) (mvtracker.py:392-399) in the flow-head kernel
+ * (mvt_update_head_bf16) and ORs 1 into *nan_flag (optional) when a coordinate became NaN (:401-404). */
 int mvt_updateformer_forward(const mvt_updater_weights* w /* host struct of device pointers */, const float* x, int ldx, int n,
-                             float* delta, int ldd, void* workspace, long long workspace_bytes, void* stream);
+                             float* delta, int ldd, float* coords, float* ffeats, int* nan_flag, void* workspace,
+                             long long workspace_bytes, void* stream);
+/* The head alone: flow head (256 -> 131 -> 131 -> 131, ReLU) on tok [rows][ldt] + track / feature update, see above.  w0 / w2 /
+ * w4 / wu fragment-major bf16 of [131][256], [131][144], [131][144], [128][128] (mvt_pack_frag_bf16, zero padded). */
+int mvt_update_head_bf16(const float* tok, int ldt, const unsigned short* w0, const float* b0, const unsigned short* w2,
+                         const float* b2, const unsigned short* w4, const float* b4, const float* gn_w, const float* gn_b,
+                         const unsigned short* wu, const float* bu, float* coords, float* ffeats, float* delta /* NULL or [rows][ldd] */,
+                         int ldd, long long rows, int hidden, int out_dim, int* nan_flag, void* stream);
 
 #ifdef __cplusplus
 }

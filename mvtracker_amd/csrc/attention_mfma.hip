@@ -40,7 +40,7 @@ template <int KS>
 __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel(
     const float* __restrict__ q, int ldq, long long q_gs, long long q_is, const float* __restrict__ k, const float* __restrict__ v,
     int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads, int bf_in,
-    int bf_out, float* __restrict__ ws) {
+    int bf_out, float* __restrict__ ws, unsigned* __restrict__ tickets) {
   // ws != null: the keys are additionally cut over gridDim.y workgroups; wave 0 leaves its (m, l, O) partial in ws and
   // attention_merge_kernel finishes the softmax (the 64 virtual x 1024 point attention is only 72 (frame, head) chunks)
   constexpr int NW = KS == 1 ? 4 : KS;
@@ -242,7 +242,46 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
 #pragma unroll
         for (int e = 0; e < 16; ++e) rr[4 + (mb * 2 + db) * 16 + e] = oacc[mb][db][e];
     }
-    return;
+    if (!tickets) return;  // attention_merge_kernel finishes
+    // Merge without a second launch: the workgroup that publishes its partial LAST (ticket counter per chunk) combines the
+    // gridDim.y partials -- always in the fixed order 0, 1, 2, ..., so the result does not depend on who arrives last -- and
+    // writes the output.  Release before the ticket (the partial is visible device-wide), acquire after it.
+    __threadfence();
+    unsigned tk = 0;
+    if (lane == 0) tk = atomicAdd(&tickets[chunk_id], 1u);
+    tk = __builtin_amdgcn_readfirstlane(tk);
+    if (tk + 1 != gridDim.y) return;
+    __threadfence();
+    if (lane == 0) tickets[chunk_id] = 0u;  // left zero for the next launch
+    {
+      const float* r0 = ws + (chunk_id * 64 + lane) * 68;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        m[mb] = __builtin_nontemporal_load(r0 + mb);
+        l[mb] = __builtin_nontemporal_load(r0 + 2 + mb);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = __builtin_nontemporal_load(r0 + 4 + (mb * 2 + db) * 16 + e);
+      }
+    }
+#pragma unroll 1
+    for (int w = 1; w < (int)gridDim.y; ++w) {
+      const float* rw = ws + ((w * nchunk + chunk_id) * 64 + lane) * 68;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float mw = __builtin_nontemporal_load(rw + mb);
+        const float mn = fmaxf(m[mb], mw);
+        const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
+        const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
+        l[mb] = l[mb] * ca + __builtin_nontemporal_load(rw + 2 + mb) * cb;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = oacc[mb][db][e] * ca + __builtin_nontemporal_load(rw + 4 + (mb * 2 + db) * 16 + e) * cb;
+        m[mb] = mn;
+      }
+    }
   }
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
@@ -338,8 +377,9 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* __res
 extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, const void* k, const void* v,
                                   int ldkv, long long k_gs, long long k_is, void* o, int ldo, int groups, int nq, int nk,
                                   int heads, int dh, int io_flags, float* workspace, void* stream) {
-  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16)) == 0);
+  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16 | MVT_ATTN_FUSED_MERGE)) == 0);
   const int bf_in = io_flags & MVT_IO_IN_BF16 ? 1 : 0, bf_out = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
+  const bool fused_merge = (io_flags & MVT_ATTN_FUSED_MERGE) != 0;
   MVT_REQUIRE(!bf_in || (ldq % 8 == 0 && ldkv % 8 == 0));  // 16-B aligned rows
   MVT_REQUIRE(!bf_out || ldo % 8 == 0);
   MVT_REQUIRE(q && k && v && o && groups > 0 && nq > 0 && nk > 0 && heads > 0 && dh == DH);
@@ -348,18 +388,20 @@ extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long l
   const long long nchunk = (long long)groups * heads * ((nq + 63) / 64);
 #define LAUNCH(KS, BLOCKS, THREADS)                                                                                        \
   hipLaunchKernelGGL((attention_mfma_kernel<KS>), dim3((unsigned)(BLOCKS)), dim3(THREADS), 0, mvt_stream(stream), (const float*)q, ldq, q_gs, \
-                     q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out, WS)
+                     q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out, WS, nullptr)
   constexpr int NSPLIT = 4;
   if (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0) {
     // too few (group, head) chunks to fill the chip: cut the keys over NSPLIT workgroups per chunk as well
     MVT_REQUIRE((uintptr_t)workspace % 16 == 0);
 #define WS workspace
+    unsigned* tickets = fused_merge ? reinterpret_cast<unsigned*>(workspace + (long long)NSPLIT * nchunk * 64 * 68) : nullptr;
     hipLaunchKernelGGL((attention_mfma_kernel<4>), dim3((unsigned)nchunk, NSPLIT), dim3(256), 0, mvt_stream(stream), (const float*)q, ldq,
                        q_gs, q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out,
-                       workspace);
+                       workspace, tickets);
 #undef WS
-    hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)mvt_cdiv(nchunk, 4)), dim3(256), 0, mvt_stream(stream), workspace, NSPLIT,
-                       nchunk, q_gs, q_is, (float*)o, ldo, nq, heads, bf_out);
+    if (!fused_merge)
+      hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)mvt_cdiv(nchunk, 4)), dim3(256), 0, mvt_stream(stream), workspace, NSPLIT,
+                         nchunk, q_gs, q_is, (float*)o, ldo, nq, heads, bf_out);
     return mvt_launch_status();
   }
 #define WS nullptr

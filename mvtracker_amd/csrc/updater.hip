@@ -30,7 +30,8 @@ inline Layout layout(long long n, long long S) {
   L.qp = take(Mp * INNER * 2);
   L.att = take(M * INNER * 2);
   L.split_ws = take((MLP / 256 + 1) * Mv * H_ * 4);
-  L.attn_ws = take(4LL * S * HEADS * 1 * 64 * 68 * 4);  // key-split partials of the 64-query virtual<-point attention
+  L.attn_ws = take(4LL * S * HEADS * 1 * 64 * 68 * 4 + (long long)S * HEADS * 4);  // key-split partials of the 64-query
+                                                                                    // virtual<-point attention + ticket counters
   L.ldh = (OUT + 3) / 4 * 4;
   L.h1 = take(Mp * L.ldh * 4);
   L.h2 = take(Mp * L.ldh * 4);
@@ -62,14 +63,17 @@ extern "C" long long mvt_updateformer_workspace_bytes(int n, int S) {
   } while (0)
 
 extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const float* x, int ldx, int n, float* delta, int ldd,
-                                        void* workspace, long long workspace_bytes, void* stream) {
-  MVT_REQUIRE(w && x && delta && workspace && n > 0);
+                                        float* coords, float* ffeats, int* nan_flag, void* workspace, long long workspace_bytes,
+                                        void* stream) {
+  MVT_REQUIRE(w && x && workspace && n > 0 && (delta || coords));
+  MVT_REQUIRE(!coords || (ffeats && w->flow0_frag.w && w->flow2_frag.w && w->flow4_frag.w && w->ffeats_updater.w && w->ffeats_norm_w &&
+                          w->ffeats_norm_b));
   MVT_REQUIRE(w->hidden == H_ && w->heads == HEADS && w->dim_head == DH_ && w->n_virtual == NV && w->out_dim == OUT);
   MVT_REQUIRE(w->depth >= 1 && w->depth <= MVT_UPDATER_MAX_DEPTH && w->S >= 1 && w->virtual_tokens);
   const int S = w->S;
   const Layout L = layout(n, S);
   MVT_REQUIRE(workspace_bytes >= L.total && ((uintptr_t)workspace % 256) == 0);
-  MVT_REQUIRE(ldx % 4 == 0 && ldx >= w->token_dim && ldd >= OUT);
+  MVT_REQUIRE(ldx % 4 == 0 && ldx >= w->token_dim && (!delta || ldd >= OUT));
   MVT_REQUIRE(w->input_transform.w && w->input_transform.N == H_ && w->input_transform.K == w->token_dim);
   MVT_REQUIRE(w->flow0.w && w->flow0.N == L.ldh && w->flow0.K == H_ && w->flow2.w && w->flow2.N == L.ldh && w->flow2.K == OUT);
   MVT_REQUIRE(w->flow4.w && w->flow4.N == OUT && w->flow4.K == OUT);
@@ -109,6 +113,8 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
   };
   const bool fuse_time = (w->fuse_attention & 1) && S <= 32, fuse_p2v = (w->fuse_attention & 2) != 0, fuse_vs = (w->fuse_attention & 4) != 0;
 
+  // ticket counters of the fused attention merge: zero on entry of the first use, left zero by every launch
+  if (hipMemsetAsync(attn_ws + 4LL * S * HEADS * 64 * 68, 0, (size_t)S * HEADS * 4, mvt_stream(stream)) != hipSuccess) return MVT_ERR_HIP_BASE;
   // tokens: input transform of the point rows, learned virtual tokens repeated over the S frames (blocks.py:456-459)
   MVT_TRY(mvt_gemm_bf16(x, ldx, w->input_transform.w, nullptr, w->input_transform.ldw, w->input_transform.b, nullptr, 0, tok, H_, (int)Mp, H_,
                         w->token_dim, MVT_ACT_NONE, 0, stream));
@@ -137,7 +143,8 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
     // ---- virtual <- point cross attention, per frame: group = frame (stride 1 row), items stride S rows
     unsigned short* qv = qkv + Mp * ld3;  // q|k|v rows of the virtual tokens
     unsigned short* av = att + Mp * INNER;
-    MVT_TRY(mvt_attention_bf16(qv, ld3, 1, S, qkv + INNER, qkv + 2 * INNER, ld3, 1, S, av, INNER, S, NV, n, HEADS, DH_, BF, attn_ws, stream));
+    MVT_TRY(mvt_attention_bf16(qv, ld3, 1, S, qkv + INNER, qkv + 2 * INNER, ld3, 1, S, av, INNER, S, NV, n, HEADS, DH_,
+                               BF | ((w->fuse_attention & 8) ? MVT_ATTN_FUSED_MERGE : 0), attn_ws, stream));
     {
       const mvt_block_next nx = next_of(vs.qkv, qv, ld3, 0, 0);
       MVT_TRY(block(v2p, vt, Mv, av, &nx, 1, split_ws));
@@ -167,6 +174,10 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
     }
     unsigned short* t_ = qkv; qkv = qkv_nx; qkv_nx = t_;
   }
+  if (coords)  // flow head + track / feature update in one launch; delta only when the caller wants to see it
+    return mvt_update_head_bf16(tok, H_, w->flow0_frag.w, w->flow0_frag.b, w->flow2_frag.w, w->flow2_frag.b, w->flow4_frag.w, w->flow4_frag.b,
+                                w->ffeats_norm_w, w->ffeats_norm_b, w->ffeats_updater.w, w->ffeats_updater.b, coords, ffeats, delta, ldd, Mp,
+                                H_, OUT, nan_flag, stream);
   // flow head (blocks.py:489): 256 -> 131 -> 131 -> 131 with ReLU; hidden activations padded to ldh columns
   MVT_TRY(mvt_gemm_bf16(tok, H_, w->flow0.w, nullptr, w->flow0.ldw, w->flow0.b, nullptr, 0, h1, L.ldh, (int)Mp, L.ldh, H_, MVT_ACT_RELU, 0, stream));
   MVT_TRY(mvt_gemm_bf16(h1, L.ldh, w->flow2.w, nullptr, w->flow2.ldw, w->flow2.b, nullptr, 0, h2, L.ldh, (int)Mp, L.ldh, OUT, MVT_ACT_RELU, 0, stream));

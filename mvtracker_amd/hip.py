@@ -73,7 +73,8 @@ SIGNATURES = {
     "mvt_window_prepare": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P],
     "mvt_window_store": [P, P, P, I, I, I, I, I, P, P, P, P],
     "mvt_updateformer_workspace_bytes": [I, I],
-    "mvt_updateformer_forward": [P, P, I, I, P, I, P, LL, P],
+    "mvt_updateformer_forward": [P, P, I, I, P, I, P, P, P, P, LL, P],
+    "mvt_update_head_bf16": [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, LL, I, I, P, P],
 }
 _RET = {"mvt_build_arch": C.c_char_p, "mvt_updateformer_workspace_bytes": C.c_longlong}
 
@@ -449,7 +450,9 @@ class UpdaterWeights(C.Structure):
                 ("S", C.c_int), ("token_dim", C.c_int), ("out_dim", C.c_int), ("fuse_attention", C.c_int), ("virtual_tokens", C.c_void_p),
                 ("input_transform", LinRows), ("flow0", LinRows), ("flow2", LinRows), ("flow4", LinRows),
                 ("time_blk", UpdaterBlock * UPDATER_MAX_DEPTH), ("v2p", UpdaterBlock * UPDATER_MAX_DEPTH),
-                ("vself", UpdaterBlock * UPDATER_MAX_DEPTH), ("p2v", UpdaterBlock * UPDATER_MAX_DEPTH)]
+                ("vself", UpdaterBlock * UPDATER_MAX_DEPTH), ("p2v", UpdaterBlock * UPDATER_MAX_DEPTH),
+                ("flow0_frag", LinFrag), ("flow2_frag", LinFrag), ("flow4_frag", LinFrag), ("ffeats_updater", LinFrag),
+                ("ffeats_norm_w", C.c_void_p), ("ffeats_norm_b", C.c_void_p)]
 
 
 def lin_frag(frag, bias, N, K):
@@ -464,10 +467,16 @@ def updateformer_workspace_bytes(n, S) -> int:
     return int(_lib.mvt_updateformer_workspace_bytes(n, S))
 
 
-def updateformer_forward(weights: UpdaterWeights, x, ldx, n, delta, ldd, workspace):
-    """EfficientUpdateFormer.forward as one library call (bf16 mode, shipped geometry); workspace: uint8 device tensor."""
-    _call("mvt_updateformer_forward", C.addressof(weights), _ptr(_f32c(x)), ldx, n, _ptr(delta), ldd, _ptr(workspace), workspace.numel(),
-          _stream())
+def updateformer_forward(weights: UpdaterWeights, x, ldx, n, delta, ldd, workspace, coords=None, ffeats=None, nan_flag=None):
+    """EfficientUpdateFormer.forward as one library call (bf16 mode, shipped geometry); workspace: uint8 device tensor.
+    With ``coords`` / ``ffeats`` the track and feature update runs inside the flow-head kernel (``delta`` may then be None)."""
+    _call("mvt_updateformer_forward", C.addressof(weights), _ptr(_f32c(x)), ldx, n, _ptr(delta), ldd, _ptr(coords), _ptr(ffeats),
+          _ptr(nan_flag), _ptr(workspace), workspace.numel(), _stream())
+
+
+def update_head_bf16(tok, ldt, w0, b0, w2, b2, w4, b4, gn_w, gn_b, wu, bu, coords, ffeats, delta, ldd, rows, hidden, out_dim, nan_flag=None):
+    _call("mvt_update_head_bf16", _ptr(tok), ldt, _ptr(w0), _ptr(b0), _ptr(w2), _ptr(b2), _ptr(w4), _ptr(b4), _ptr(gn_w), _ptr(gn_b), _ptr(wu),
+          _ptr(bu), _ptr(coords), _ptr(ffeats), _ptr(delta), ldd, rows, hidden, out_dim, _ptr(nan_flag), _stream())
 
 
 ATTN_TIME, ATTN_FRAME = 1, 2

@@ -123,8 +123,10 @@ class MVTracker(nn.Module):
         self.bf16_tokens = os.environ.get("MVT_BF16_TOK", "1") != "0"  # bf16 mode: q/k/v and attention outputs stored as bf16
         self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
         self.bf16_store = os.environ.get("MVT_BF16_STORE", "1") != "0"  # bf16 mode: bf16 feature rows in the frame store
-        # attention inside the block kernels: bit 0 time, bit 1 point<-virtual, bit 2 virtual self (bit-identical to the separate launches)
-        self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "7"))
+        # attention inside the block kernels: bit 0 time, bit 1 point<-virtual, bit 2 virtual self; bit 3: in-kernel merge of the
+        # key-split virtual<-point attention (all bit-identical to the separate launches)
+        self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "15"))
+        self.fuse_head = os.environ.get("MVT_FUSE_HEAD", "1") != "0"  # flow head + track / feature update in one kernel
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
         d = self.updateformer_input_dim
@@ -316,6 +318,21 @@ class MVTracker(nn.Module):
 
         w.input_transform = rows(u + "input_transform")
         w.flow0, w.flow2, w.flow4 = rows(u + "flow_head.0", True), rows(u + "flow_head.2", True), rows(u + "flow_head.4")
+
+        def frag_of(name, kpad):  # fragment-major bf16 of a [N][K] linear, K zero-padded to kpad (a multiple of 16)
+            wt, b = sd[name + ".weight"], sd[name + ".bias"].contiguous()
+            n, k = wt.shape
+            hi = matrix(wt)[0]  # [n][round_up(k, 64)], zero padded
+            fr = torch.empty(_round_up(n, 32) * kpad, device=wt.device, dtype=torch.int16)
+            hip.pack_frag_bf16(hi, hi.shape[1], n, kpad, fr)
+            keep.extend([fr, b])
+            return hip.lin_frag(fr, b, n, kpad)
+
+        w.flow0_frag, w.flow2_frag, w.flow4_frag = frag_of(u + "flow_head.0", h), frag_of(u + "flow_head.2", 144), frag_of(u + "flow_head.4", 144)
+        w.ffeats_updater = frag_of("ffeats_updater.0", self.latent_dim)
+        gw, gb = sd["ffeats_norm.weight"].contiguous(), sd["ffeats_norm.bias"].contiguous()
+        keep.extend([gw, gb])
+        w.ffeats_norm_w, w.ffeats_norm_b = gw.data_ptr(), gb.data_ptr()
 
         def frag(name):
             _, b, n, k = pk[name]
@@ -543,11 +560,16 @@ class MVTracker(nn.Module):
         self._ln_lin(pk, p + ".mlp.fc1", tok, rows, hbuf, 4 * h, xn, act=hip.ACT_GELU_TANH)
         self._lin(pk, p + ".mlp.fc2", hbuf, 4 * h, rows, tok, h, R=tok, ldr=h)
 
-    def _update_former(self, pk, x, ldx, n, delta, ldd):
+    def _update_former(self, pk, x, ldx, n, delta, ldd, coords=None, ffeats=None, nan_flag=None):
+        """delta = updater(x).  With ``coords`` / ``ffeats`` (composite path only) the track / feature update of mvtracker.py:392-399
+        is applied inside the same library call and True is returned."""
         if "updater_struct" in pk:  # the whole transformer as ONE library call (mvt_updateformer_forward)
             nbytes = hip.updateformer_workspace_bytes(n, self.S)
             ws = self._workspace(nbytes, x.device)
-            return hip.updateformer_forward(pk["updater_struct"], x, ldx, n, delta, ldd, ws)
+            fused = coords is not None and self.fuse_head
+            hip.updateformer_forward(pk["updater_struct"], x, ldx, n, delta, ldd, ws, coords if fused else None,
+                                     ffeats if fused else None, nan_flag if fused else None)
+            return fused
         if self.precision == "bf16" and self.hidden == 256 and self.num_heads * self.dim_head == 288 and self.fuse_blocks:
             return self._update_former_fused(pk, x, ldx, n, delta, ldd)
         S, h, nv, H, dh = self.S, self.hidden, self.nv, self.num_heads, self.dim_head
@@ -771,14 +793,17 @@ class MVTracker(nn.Module):
             hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0, 1,
                                 T, K, fcorr, Fc, 0)
             hip.token_assemble(coords, fcorr, Fc, ffeats, C, mask_vis, pos, pk["time_embed"], n, S, E, x, ldx)
-            self._update_former(pk, x, ldx, n, delta, ldd)
+            # (the delta tensor itself only leaves the fused head for tracing)
+            updated = self._update_former(pk, x, ldx, n, delta if trace is not None else None, ldd, coords, ffeats, nan_flag) \
+                if "updater_struct" in pk and self.fuse_head else self._update_former(pk, x, ldx, n, delta, ldd)
             if trace is not None:
                 trace.setdefault("knn_idx", []).append(idx.clone())
                 trace.setdefault("fcorrs", []).append(fcorr.clone())
                 trace.setdefault("tokens", []).append(x[:, :D].reshape(n, S, D).clone())
                 trace.setdefault("delta", []).append(delta[:, :self.out_dim].reshape(n, S, -1).clone())
-            hip.delta_split(delta, ldd, *pk["ffeats_norm"], coords, dn, n * S, C, nan_flag)
-            self._lin(pk, "ffeats_updater.0", dn, C, n * S, ffeats, C, hip.ACT_GELU_ERF, R=ffeats, ldr=C)
+            if not updated:
+                hip.delta_split(delta, ldd, *pk["ffeats_norm"], coords, dn, n * S, C, nan_flag)
+                self._lin(pk, "ffeats_updater.0", dn, C, n * S, ffeats, C, hip.ACT_GELU_ERF, R=ffeats, ldr=C)
             if trace is not None:  # (the intermediate estimates only feed the training loss upstream)
                 preds.append(coords.clone())
         if trace is None:

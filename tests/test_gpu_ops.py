@@ -1071,3 +1071,73 @@ def test_avgpool2_and_knn1_gather_bf16(hip):
     hip.knn1_gather(G(fvec), P, C, keys, nq, 1, 1, feat)
     _, ridx = O.knn_exact(1, xyz[1:2, :, :3], q[None])
     assert torch.equal(feat.cpu(), fvec[1][ridx[0, :, 0]].float())
+
+
+@pytest.mark.parametrize("rows", [12288, 100])
+def test_update_head_bf16_matches_unfused_sequence(hip, rows):
+    """mvt_update_head_bf16 (flow head + track / feature update in one launch) against the unfused library sequence it replaces
+    (three mvt_gemm_bf16, mvt_delta_split, one more mvt_gemm_bf16) on identical inputs: the same bf16 operand roundings, fp32
+    accumulation in a different order -> agreement to fp32 rounding noise; and against an fp64 torch evaluation at bf16 accuracy."""
+    g = torch.Generator().manual_seed(rows)
+    C, OUT, CF = 256, 131, 128
+    tok = torch.randn(rows, C, generator=g)
+    W0, W2, W4 = torch.randn(OUT, C, generator=g) / 16, torch.randn(OUT, OUT, generator=g) / 11, torch.randn(OUT, OUT, generator=g) / 11
+    Wu = torch.randn(CF, CF, generator=g) / 11
+    b0, b2, b4, bu = (torch.randn(n, generator=g) * 0.1 for n in (OUT, OUT, OUT, CF))
+    gw, gb = 1 + 0.1 * torch.randn(CF, generator=g), 0.1 * torch.randn(CF, generator=g)
+    coords0, ff0 = torch.randn(rows, 3, generator=g), torch.randn(rows, CF, generator=g)
+
+    def rowsw(w, pad_n):
+        n, k = w.shape
+        wp = pad_w(w)
+        if pad_n:
+            wp = torch.cat([wp, torch.zeros(pad_n - n, wp.shape[1])], 0)
+        return split(hip, G(wp), lo=False)[0]
+
+    def frag(w, kpad):
+        hi = split(hip, G(pad_w(w)), lo=False)[0]
+        fr = torch.empty((w.shape[0] + 31) // 32 * 32 * kpad, device=DEV, dtype=torch.int16)
+        hip.pack_frag_bf16(hi, hi.shape[1], w.shape[0], kpad, fr)
+        return fr
+
+    # unfused
+    h0, h2, h4, hu = rowsw(W0, 132), rowsw(W2, 132), rowsw(W4, 0), rowsw(Wu, 0)
+    pad1 = lambda b: G(torch.cat([b, torch.zeros(132 - OUT)]))
+    tg = G(tok)
+    h1 = torch.empty(rows, 132, device=DEV)
+    h2t = torch.empty(rows, 132, device=DEV)
+    delta = torch.empty(rows, 132, device=DEV)
+    hip.gemm_bf16(tg, C, h0, None, h0.shape[1], pad1(b0), None, 0, h1, 132, rows, 132, C, 1)
+    hip.gemm_bf16(h1, 132, h2, None, h2.shape[1], pad1(b2), None, 0, h2t, 132, rows, 132, OUT, 1)
+    hip.gemm_bf16(h2t, 132, h4, None, h4.shape[1], G(b4), None, 0, delta, 132, rows, OUT, OUT, 0)
+    c_ref, f_ref = G(coords0).clone(), G(ff0).clone()
+    dn = torch.empty(rows, CF, device=DEV)
+    hip.delta_split(delta, 132, G(gw), G(gb), c_ref, dn, rows, CF, None)
+    hip.gemm_bf16(dn, CF, hu, None, hu.shape[1], G(bu), f_ref, CF, f_ref, CF, rows, CF, CF, 3)
+    # fused
+    c_f, f_f = G(coords0).clone(), G(ff0).clone()
+    d_f = torch.zeros(rows, 132, device=DEV)
+    flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+    hip.update_head_bf16(tg, C, frag(W0, 256), G(b0), frag(W2, 144), G(b2), frag(W4, 144), G(b4), G(gw), G(gb), frag(Wu, 128), G(bu), c_f, f_f,
+                         d_f, 132, rows, C, OUT, flag)
+    torch.cuda.synchronize()
+    sc = delta[:, :OUT].abs().max().item()
+    assert (d_f[:, :OUT] - delta[:, :OUT]).abs().max().item() < 2e-5 * sc
+    assert (c_f - c_ref).abs().max().item() < 2e-5 * sc
+    assert (f_f - f_ref).abs().max().item() < 2e-3  # (GroupNorm amplifies the 1e-5 delta noise before a bf16 rounding of dn)
+    assert int(flag.item()) == 0
+    # fp64 evaluation
+    t64 = tok.double()
+    d64 = torch.relu(torch.relu(t64 @ W0.double().t() + b0.double()) @ W2.double().t() + b2.double()) @ W4.double().t() + b4.double()
+    assert (d_f[:, :OUT].cpu().double() - d64).abs().max().item() < 3e-2 * d64.abs().max().item()
+    dnn = torch.nn.functional.group_norm(d64[:, 3:], 1, gw.double(), gb.double(), 1e-5)
+    f64 = ff0.double() + torch.nn.functional.gelu(dnn @ Wu.double().t() + bu.double())
+    assert (f_f.cpu().double() - f64).abs().max().item() < 6e-2
+    assert (c_f.cpu().double() - (coords0.double() + d64[:, :3])).abs().max().item() < 3e-2 * d64.abs().max().item()
+    # NaN guard
+    c_n = G(coords0).clone()
+    c_n[5, 1] = float("nan")
+    hip.update_head_bf16(tg, C, frag(W0, 256), G(b0), frag(W2, 144), G(b2), frag(W4, 144), G(b4), G(gw), G(gb), frag(Wu, 128), G(bu), c_n,
+                         G(ff0).clone(), None, 0, rows, C, OUT, flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
