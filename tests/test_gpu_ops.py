@@ -1124,7 +1124,7 @@ def test_update_head_bf16_matches_unfused_sequence(hip, rows):
     sc = delta[:, :OUT].abs().max().item()
     assert (d_f[:, :OUT] - delta[:, :OUT]).abs().max().item() < 2e-5 * sc
     assert (c_f - c_ref).abs().max().item() < 2e-5 * sc
-    assert (f_f - f_ref).abs().max().item() < 2e-3  # (GroupNorm amplifies the 1e-5 delta noise before a bf16 rounding of dn)
+    assert (f_f - f_ref).abs().max().item() < 8e-3  # (GroupNorm amplifies the 1e-5 delta noise into bf16 rounding flips of dn: ~7e-4 each)
     assert int(flag.item()) == 0
     # fp64 evaluation
     t64 = tok.double()
