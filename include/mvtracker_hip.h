@@ -368,6 +368,15 @@ int mvt_window_prepare(const float* qxyz, const int* qt, const float* feat_init,
 int mvt_window_store(const float* coords, const float* vis, const long long* order, int n, int S, int w, int T, int N, float* traj,
                      float* vis_logit, float* vis_prob, void* stream);
 
+/* Per-track evaluation metrics (mvtracker/evaluation/metrics.py:10-58, 61-171, 327-330; query_mode "first"): one row of
+ * 11 + 2K floats per track -- movement, visible frames, occlusion accuracy (all / gt-occluded / gt-visible), average Jaccard,
+ * average pts-within, MTE (lower median), ATE, FDE, survival, then pts-within[K] and Jaccard[K] (fractions, NaN where the
+ * reference divides by zero).  gt_tracks / pred_tracks [T][N][D] (D = 2 or 3), gt_visible / pred_occluded [T][N] bytes,
+ * query_frame [N] int32, thresholds: HOST array of K <= 8 distances.  T <= 1024. */
+int mvt_track_metrics(const float* gt_tracks, const float* pred_tracks, const unsigned char* gt_visible,
+                      const unsigned char* pred_occluded, const int* query_frame, int T, int N, int D, const float* thresholds, int K,
+                      float survival_threshold, float* out, int ldo, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Composite entry points: one C call per stage of the hot path instead of one per kernel, so that a
  * non-Python caller can run the updater as ONE operation and the launch order lives in the library, not in host glue.

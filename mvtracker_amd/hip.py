@@ -72,6 +72,7 @@ SIGNATURES = {
     "mvt_attn_block_fused_bf16": [P, I, P, P, P, P, P, P, P, I, P, I, LL, I, P, P],
     "mvt_window_prepare": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P],
     "mvt_window_store": [P, P, P, I, I, I, I, I, P, P, P, P],
+    "mvt_track_metrics": [P, P, P, P, P, I, I, I, P, I, F, P, I, P],
     "mvt_updateformer_workspace_bytes": [I, I],
     "mvt_updateformer_forward": [P, P, I, I, P, I, P, P, P, P, LL, P],
     "mvt_update_head_bf16": [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, LL, I, I, P, P],
@@ -498,3 +499,12 @@ def attn_block_fused_bf16(x, ldx, kind, S, q, ldq, k, v, ldkv, n_keys, wo, bo, w
                            nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)), 1 if nx["y"].dtype == torch.bfloat16 else 0)
     _call("mvt_attn_block_fused_bf16", _ptr(x), ldx, C.addressof(at), _ptr(wo), _ptr(bo), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), H,
           C.cast(arr, C.c_void_p), len(nexts), M, Cc, _ptr(ws), _stream())
+
+
+def track_metrics(gt_tracks, pred_tracks, gt_visible, pred_occluded, query_frame, T, N, D, thresholds, survival_threshold, out):
+    """Per-track evaluation metrics; gt_visible / pred_occluded uint8 (T,N), query_frame int32 (N), out (N, 11 + 2K) fp32."""
+    assert gt_visible.dtype == torch.uint8 and pred_occluded.dtype == torch.uint8 and query_frame.dtype == torch.int32
+    K = len(thresholds)
+    th = (C.c_float * K)(*[float(t) for t in thresholds])
+    _call("mvt_track_metrics", _ptr(_f32c(gt_tracks)), _ptr(_f32c(pred_tracks)), _ptr(gt_visible), _ptr(pred_occluded), _ptr(query_frame),
+          T, N, D, C.cast(th, C.c_void_p), K, float(survival_threshold), _ptr(out), out.shape[1], _stream())

@@ -10,6 +10,7 @@ bookkeeping on device tensors.
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 from typing import Optional, Tuple
 
@@ -32,6 +33,19 @@ def _bilinear_sample_depth(depth: torch.Tensor, x: torch.Tensor, y: torch.Tensor
     flat = depth.reshape(-1)
     return ((x1 - x) * (y1 - y) * flat[cy0 * W + cx0] + (x - x0) * (y1 - y) * flat[cy0 * W + cx1]
             + (x1 - x) * (y - y0) * flat[cy1 * W + cx0] + (x - x0) * (y - y0) * flat[cy1 * W + cx1])
+
+
+def _bilinear_sample_depth_multi(depths: torch.Tensor, v: torch.Tensor, t: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """``_bilinear_sample_depth`` for points that live in different (view, frame) depth maps: depths (V,T,H,W), v,t,x,y (M,)."""
+    V, T, H, W = depths.shape
+    x0, y0 = torch.floor(x), torch.floor(y)
+    x1, y1 = x0 + 1, y0 + 1
+    cx0, cx1 = x0.clamp(0, W - 1).long(), x1.clamp(0, W - 1).long()
+    cy0, cy1 = y0.clamp(0, H - 1).long(), y1.clamp(0, H - 1).long()
+    flat = depths.reshape(-1)
+    base = (v * T + t) * (H * W)
+    return ((x1 - x) * (y1 - y) * flat[base + cy0 * W + cx0] + (x - x0) * (y1 - y) * flat[base + cy0 * W + cx1]
+            + (x1 - x) * (y - y0) * flat[base + cy1 * W + cx0] + (x - x0) * (y - y0) * flat[base + cy1 * W + cx1])
 
 
 def points_on_a_grid(size: int, extent: Tuple[float, float], center=None, device="cpu") -> torch.Tensor:
@@ -74,9 +88,18 @@ class EvaluationPredictor(torch.nn.Module):
         self.sift_size = sift_size
         self.num_uniformly_sampled_pts = num_uniformly_sampled_pts
         self.n_iters = n_iters
+        self.single_point_streams = 4  # HIP streams the per-query forwards of single_point mode are spread over
+        self._stream_pool = {}
         self.model.eval()
 
     # ---- helpers -------------------------------------------------------------------------
+    def _streams(self, dev, n):
+        key = (dev.type, dev.index)
+        pool = self._stream_pool.setdefault(key, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=dev))
+        return pool[:n]
+
     @staticmethod
     def _invert(intrs, extrs):
         """K^-1 (V,T,3,3) and rows 0..2 of [R|t]^-1 (V,T,3,4) through the library (fp64 closed form)."""
@@ -166,8 +189,8 @@ class EvaluationPredictor(torch.nn.Module):
         if self.single_point:  # :191-339, one forward per query with its local grids
             traj_e = torch.zeros(1, T, num_points, 3, device=dev)
             vis_e = torch.zeros(1, T, num_points, device=dev)
-            qt = query_points_3d[0, :, 0].long().cpu().tolist()
-            qh = torch.cat([query_points_3d[0, :, 1:], torch.ones(num_points, 1, device=dev)], 1)
+            qt_d = query_points_3d[0, :, 0].long()
+            qt = qt_d.cpu().tolist()
             # The N forwards differ only in their queries: encoder, feature pyramid and point clouds are built ONCE and
             # shared (the reference re-encodes the clip for every query).  Every forward reads
             # frames >= its own first query frame only, so one store from the earliest query frame serves them all.
@@ -177,24 +200,60 @@ class EvaluationPredictor(torch.nn.Module):
                 r0 = rgbs[0].contiguous() if rgbs.dtype == torch.uint8 else f32(rgbs[0])
                 fwd["frame_store"] = self.model.build_frame_store(r0, f32(depths[0]), f32(intrs[0]), f32(extrs[0]),
                                                                   t0=t_first)
-            for i in range(num_points):
-                t = qt[i]
-                rows = []
-                if self.local_grid_size > 0:
+            # Local support grids of ALL queries in one pass (:221-252): project every query into every view at its own frame
+            # (one device op, ONE readback instead of two .item() syncs per view and query), lay the grids out and clip them to
+            # the image on the host, then sample depth / unproject all surviving pixels at once on the device.
+            local_rows = [[] for _ in range(num_points)]
+            if self.local_grid_size > 0 and num_points > 0:
+                qh = torch.cat([query_points_3d[0, :, 1:], torch.ones(num_points, 1, device=dev)], 1)
+                cam = torch.einsum("vnij,nj->vni", extrs[0][:, qt_d], qh)
+                ph = torch.einsum("vnij,vnj->vni", intrs[0][:, qt_d], cam)
+                centres = (ph[..., :2] / ph[..., 2:]).cpu()  # (V, N, 2) pixel (x, y)
+                pix_l, vid_l, fid_l, counts = [], [], [], []
+                for i in range(num_points):
                     for v in range(V):
-                        cam = extrs[0, v, t] @ qh[i]
-                        ph = intrs[0, v, t] @ cam
-                        px, py = (ph[0] / ph[2]).item(), (ph[1] / ph[2]).item()
-                        pix = points_on_a_grid(self.local_grid_size, (self.local_extent, self.local_extent), (py, px), dev)
+                        px, py = centres[v, i, 0].item(), centres[v, i, 1].item()
+                        pix = points_on_a_grid(self.local_grid_size, (self.local_extent, self.local_extent), (py, px), "cpu")
                         ok = (pix[:, 0] >= 0) & (pix[:, 0] < width) & (pix[:, 1] >= 0) & (pix[:, 1] < height)
-                        if not bool(ok.any()):
-                            continue
-                        rows.append(self._support_rows(depths[0, v, t, 0], pix[ok], kinv[v, t], einv[v, t], t))
-                q_i = torch.cat([query_points_3d[0, i:i + 1]] + rows + [support], 0)[None]
-                res = self.model(rgbs, depths=depths, query_points=q_i, **fwd)
-                traj_e[:, :, i] = res["traj_e"][:, :, 0]
-                vis_e[:, :, i] = res["vis_e"][:, :, 0]
-                nan_flags.append(getattr(self.model, "last_nan_flag", None))
+                        k = int(ok.sum())
+                        counts.append(k)
+                        if k:
+                            pix_l.append(pix[ok])
+                            vid_l.append(torch.full((k,), v, dtype=torch.long))
+                            fid_l.append(torch.full((k,), qt[i], dtype=torch.long))
+                if pix_l:
+                    pix_all = torch.cat(pix_l).to(dev)
+                    vid, fid = torch.cat(vid_l).to(dev), torch.cat(fid_l).to(dev)
+                    z = _bilinear_sample_depth_multi(depths[0, :, :, 0], vid, fid, pix_all[:, 0], pix_all[:, 1])
+                    phm = torch.cat([pix_all, torch.ones_like(pix_all[:, :1])], 1)
+                    camm = torch.einsum("mij,mj->mi", kinv[vid, fid], phm) * z[:, None]
+                    ei = einv[vid, fid]
+                    world = torch.einsum("mij,mj->mi", ei[:, :, :3], camm) + ei[:, :, 3]
+                    rows_all = torch.cat([fid[:, None].to(world.dtype), world], 1)
+                    o = 0
+                    for i in range(num_points):
+                        for v in range(V):
+                            k = counts[i * V + v]
+                            if k:
+                                local_rows[i].append(rows_all[o:o + k])
+                                o += k
+            # The per-query forwards are independent (each has its own 64 virtual tracks, :254-275) and tiny -- a few hundred
+            # tracks, pure launch-latency chains -- so they are issued round-robin on a few HIP streams and overlap on the GPU.
+            n_streams = max(1, min(self.single_point_streams, num_points)) if dev.type == "cuda" else 1
+            main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+            streams = self._streams(dev, n_streams) if n_streams > 1 else []
+            for s_ in streams:
+                s_.wait_stream(main)
+            for i in range(num_points):
+                ctx = torch.cuda.stream(streams[i % n_streams]) if streams else contextlib.nullcontext()
+                with ctx:  # (everything of query i, its input rows included, is enqueued on its own stream)
+                    q_i = torch.cat([query_points_3d[0, i:i + 1]] + local_rows[i] + [support], 0)[None]
+                    res = self.model(rgbs, depths=depths, query_points=q_i, **fwd)
+                    traj_e[:, :, i] = res["traj_e"][:, :, 0]
+                    vis_e[:, :, i] = res["vis_e"][:, :, 0]
+                    nan_flags.append(getattr(self.model, "last_nan_flag", None))
+            for s_ in streams:
+                main.wait_stream(s_)
         else:  # joint mode, :341-360
             q = torch.cat([query_points_3d[0], support], 0)[None]
             res = self.model(rgbs, depths=depths, query_points=q, **fwd)

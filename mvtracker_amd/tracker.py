@@ -636,9 +636,9 @@ class MVTracker(nn.Module):
     def _flow_scratch(self, rows, ld, dev):
         """Hidden activations of the flow head, (rows, ld) with ld = round_up(out_dim, 4): the GEMMs write out_dim columns, the
         pad columns are read as K padding by the next layer and must be zero -- zeroed once, then reused by every call."""
-        key = (rows, ld, dev.type, dev.index)
+        key = (rows, ld, dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
         if key not in self._scratch:
-            if len(self._scratch) > 8:
+            if len(self._scratch) > 32:
                 self._scratch.clear()
             self._scratch[key] = (torch.zeros(rows, ld, device=dev), torch.zeros(rows, ld, device=dev))
         return self._scratch[key]

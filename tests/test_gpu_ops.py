@@ -1,6 +1,8 @@
 """Parity of every entry point of libmvtracker_hip.so against the oracle / plain torch fp32-fp64
 references on identical inputs.  Runs on the MI355X box only (`-m gpu`); all calls go through the C ABI."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -8,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # (test_oracle_golden helpers)
 
 from mvtracker_amd import synth  # noqa: E402
 from oracle import mvt_oracle as O  # noqa: E402
@@ -1141,3 +1144,49 @@ def test_update_head_bf16_matches_unfused_sequence(hip, rows):
                          G(ff0).clone(), None, 0, rows, C, OUT, flag)
     torch.cuda.synchronize()
     assert int(flag.item()) == 1
+
+
+# ----------------------------------------------------------------------------------------- round 2: metrics post-processing (f4)
+@pytest.mark.parametrize("name", ["3d", "2d"])
+def test_metrics_golden(hip, golden, name):
+    """evaluate_predictions on the device (one mvt_track_metrics launch + masked means) against the REFERENCE's tables
+    (tests/golden/make_golden_metrics.py) and the oracle; integer track ids bit-exact."""
+    from mvtracker_amd import metrics
+    from oracle import metrics_oracle as MO
+    from test_oracle_golden import METRIC_KW, check_metrics_against_golden
+    g = golden("metrics_eval")
+    args = (g[f"{name}_gt"], g[f"{name}_vis"], g[f"{name}_pred"], g[f"{name}_pocc"], g[f"{name}_qp"])
+    res, pt = metrics.evaluate_predictions(*args, **METRIC_KW[name], device=DEV)
+    check_metrics_against_golden(g, name, res, pt)
+    # per-track table against the oracle's float32 evaluation for EVERY track (also those outside all masks)
+    gt_vis = args[1] & (np.arange(args[0].shape[0])[:, None] >= args[4][:, 0][None, :])
+    tm = MO.track_metrics(args[0], gt_vis, args[2], args[3], args[4], METRIC_KW[name]["distance_thresholds"], METRIC_KW[name]["survival_distance_threshold"])
+    names, table, movement, nvis, _ = metrics.per_track_metrics(*args, METRIC_KW[name]["distance_thresholds"],
+                                                                METRIC_KW[name]["survival_distance_threshold"], device=DEV)
+    th = table.cpu().numpy()
+    for j, k in enumerate(names):
+        ref = tm[k]
+        ok = (np.isnan(ref) & np.isnan(th[:, j])) | (np.abs(ref - th[:, j]) <= 1e-5 * (1 + np.abs(ref)))
+        assert ok.all(), (k, ref[~ok][:3], th[~ok, j][:3])
+    assert np.allclose(movement.cpu().numpy(), MO.point_movement(args[0], gt_vis), rtol=1e-5, atol=1e-6)
+    assert np.array_equal(nvis.cpu().numpy().astype(np.int64), gt_vis.sum(0))
+
+
+def test_metrics_long_clip_and_evaluate_3dpt(hip):
+    """T > 64 (several 64-frame steps: carried movement, median over > 64 values) against the oracle, and evaluate_3dpt's flat dict."""
+    from mvtracker_amd import metrics
+    from oracle import metrics_oracle as MO
+    rng = np.random.default_rng(9)
+    T, N = 150, 33
+    gt = (rng.uniform(-1, 1, (1, N, 3)) + np.cumsum(rng.standard_normal((T, N, 3)) * 0.02, 0)).astype(np.float32)
+    vis = rng.uniform(size=(T, N)) < 0.7
+    qt = rng.integers(0, 70, size=N)
+    vis[qt, np.arange(N)] = True
+    pred = (gt + rng.standard_normal((T, N, 3)) * 0.05).astype(np.float32)
+    pvis = vis ^ (rng.uniform(size=(T, N)) < 0.1)
+    qp = np.concatenate([qt[:, None].astype(np.float32), gt[qt, np.arange(N)]], -1).astype(np.float32)
+    got = metrics.evaluate_3dpt(gt, vis, pred, pvis, "kubric-multiview", 2.0, qp, add_per_track_results=False, device=DEV)
+    ref = MO.evaluate_3dpt(gt, vis, pred, pvis, "kubric-multiview", 2.0, qp)
+    assert sorted(got) == sorted(ref)
+    for k in ref:
+        assert (np.isnan(ref[k]) and np.isnan(got[k])) or abs(ref[k] - got[k]) <= 0.011, (k, ref[k], got[k])

@@ -273,3 +273,43 @@ def test_window_corr_c128(golden):
     fm = window_corr_c128_inputs(g)
     pyr = O.window_corr_pyramid(T(fm), 4)
     close(O.window_corr_sample(pyr, T(g["targets"]), T(g["coords"]), 4), g["out_r4"], rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------- metrics post-processing (f4)
+METRIC_KW = {"3d": dict(distance_thresholds=[0.05, 0.1, 0.2, 0.4, 0.8], survival_distance_threshold=0.5, static_threshold=0.01,
+                        dynamic_threshold=0.1, very_dynamic_threshold=2.0),
+             "2d": dict(distance_thresholds=[1, 2, 4, 8, 16], survival_distance_threshold=50, static_threshold=None,
+                        dynamic_threshold=None, very_dynamic_threshold=None)}
+
+
+def check_metrics_against_golden(g, name, results, per_track, tol=0.011):
+    """results: column -> {metric: value}; the reference table is rounded to 2 decimals (DataFrame.round(2))."""
+    cols, idx, table = list(g[f"{name}_columns"]), list(g[f"{name}_index"]), g[f"{name}_table"]
+    assert sorted(results) == sorted(cols), (sorted(results), sorted(cols))
+    for ci, col in enumerate(cols):
+        assert sorted(results[col]) == sorted(idx)
+        for ri, metric in enumerate(idx):
+            ref, got = table[ri, ci], results[col][metric]
+            assert (np.isnan(ref) and np.isnan(got)) or abs(ref - got) <= tol, (col, metric, ref, got)
+    n_checked = 0
+    for key in g.files:
+        if key.startswith(f"{name}_pt__"):
+            _, col, k = key.split("__")
+            ref, got = g[key], np.asarray(per_track[col][k])
+            assert ref.shape == got.shape, key
+            if k == "indices":
+                assert np.array_equal(ref, got)  # integer track ids: bit-exact
+            else:
+                ok = (np.isnan(ref) & np.isnan(got)) | (np.abs(ref - got) <= tol + 1e-4 * np.abs(ref))
+                assert ok.all(), (key, ref[~ok][:4], got[~ok][:4])
+            n_checked += 1
+    assert n_checked > 10
+
+
+@pytest.mark.parametrize("name", ["3d", "2d"])
+def test_metrics_oracle(golden, name):
+    from oracle import metrics_oracle as MO
+    g = golden("metrics_eval")
+    res, pt = MO.evaluate_predictions(g[f"{name}_gt"], g[f"{name}_vis"], g[f"{name}_pred"], g[f"{name}_pocc"], g[f"{name}_qp"],
+                                      **METRIC_KW[name])
+    check_metrics_against_golden(g, name, res, pt)
