@@ -88,7 +88,7 @@ class EvaluationPredictor(torch.nn.Module):
         self.sift_size = sift_size
         self.num_uniformly_sampled_pts = num_uniformly_sampled_pts
         self.n_iters = n_iters
-        self.single_point_streams = 4  # HIP streams the per-query forwards of single_point mode are spread over
+        self.single_point_streams = 8  # HIP streams the per-query forwards of single_point mode are spread over
         self._stream_pool = {}
         self.model.eval()
 
