@@ -164,11 +164,17 @@ int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 whe
  *                  with context token j of frame t at row j * S + t.  M < 4096: two-launch split path, workspace required. */
 #define MVT_ATTN_TIME 1
 #define MVT_ATTN_FRAME 2
+/*   MVT_ATTN_PARTIALS: the attention was computed key-split by mvt_attention_bf16(MVT_ATTN_PARTIALS_ONLY) (64 queries per
+ *                  frame, the virtual tokens: M = 64 * S); the kernel combines the n_splits partial states itself -- same
+ *                  arithmetic and order as the merge launch it replaces -- instead of reading a merged attention tensor. */
+#define MVT_ATTN_PARTIALS 3
 typedef struct mvt_block_attn {
   int kind, S, n_keys, heads, dim_head, ldq, ldkv;
   const unsigned short* q;
   const unsigned short* k;
   const unsigned short* v;
+  const float* partials; /* MVT_ATTN_PARTIALS: the workspace of mvt_attention_bf16 */
+  int n_splits;
 } mvt_block_attn;
 int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn* attn, const unsigned short* wo, const float* bo,
                               const unsigned short* w1, const float* b1, const unsigned short* w2, const float* b2, int H,
@@ -353,6 +359,10 @@ int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, c
  * partial (fixed combination order: deterministic) instead of by a second launch.  The workspace then carries a tail of
  * groups*heads*ceil(nq/64) uint32 ticket counters after the partials; they must be ZERO on entry and are left zero. */
 #define MVT_ATTN_FUSED_MERGE 4
+/* io_flags bit: stop after the key-split partials (no merge launch, `o` is not written); the consumer combines them
+ * (mvt_attn_block_fused_bf16, MVT_ATTN_PARTIALS).  Only valid when the key-split path is taken (nk >= 512, < 256 chunks). */
+#define MVT_ATTN_PARTIALS_ONLY 8
+#define MVT_ATTN_NSPLIT 4 /* key splits of that path */
 /* x[(n*S+s)*ld + 0:C] = v[n][0:C] for all s  (virtual-token broadcast, blocks.py:458-459). */
 int mvt_broadcast_rows(const float* v, float* x, int ld, int n, int S, int C, void* stream);
 
@@ -414,7 +424,8 @@ typedef struct mvt_updater_weights {
   int depth, hidden, heads, dim_head, n_virtual, S, token_dim, out_dim;
   int fuse_attention; /* bit 0: time attention, bit 1: point<-virtual, bit 2: virtual self attention run inside the block kernels
                          (mvt_attn_block_fused_bf16) instead of as separate launches; bit 3: the key-split virtual<-point attention
-                         merges its partials itself (MVT_ATTN_FUSED_MERGE); results are bit-identical either way */
+                         merges its partials itself (MVT_ATTN_FUSED_MERGE); bit 4: the virtual<-point block combines the partials
+                         (MVT_ATTN_PARTIALS, no merge launch); results are bit-identical either way */
   const float* virtual_tokens; /* [n_virtual][hidden] */
   mvt_lin_rows input_transform, flow0, flow2, flow4;
   mvt_updater_block time_blk[MVT_UPDATER_MAX_DEPTH], v2p[MVT_UPDATER_MAX_DEPTH], vself[MVT_UPDATER_MAX_DEPTH], p2v[MVT_UPDATER_MAX_DEPTH];

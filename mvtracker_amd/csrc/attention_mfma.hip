@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* __res
 extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, const void* k, const void* v,
                                   int ldkv, long long k_gs, long long k_is, void* o, int ldo, int groups, int nq, int nk,
                                   int heads, int dh, int io_flags, float* workspace, void* stream) {
-  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16 | MVT_ATTN_FUSED_MERGE)) == 0);
+  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16 | MVT_ATTN_FUSED_MERGE | MVT_ATTN_PARTIALS_ONLY)) == 0);
+  const bool partials_only = (io_flags & MVT_ATTN_PARTIALS_ONLY) != 0;
   const int bf_in = io_flags & MVT_IO_IN_BF16 ? 1 : 0, bf_out = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
   const bool fused_merge = (io_flags & MVT_ATTN_FUSED_MERGE) != 0;
   MVT_REQUIRE(!bf_in || (ldq % 8 == 0 && ldkv % 8 == 0));  // 16-B aligned rows
@@ -389,7 +390,8 @@ extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long l
 #define LAUNCH(KS, BLOCKS, THREADS)                                                                                        \
   hipLaunchKernelGGL((attention_mfma_kernel<KS>), dim3((unsigned)(BLOCKS)), dim3(THREADS), 0, mvt_stream(stream), (const float*)q, ldq, q_gs, \
                      q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out, WS, nullptr)
-  constexpr int NSPLIT = 4;
+  constexpr int NSPLIT = MVT_ATTN_NSPLIT;
+  MVT_REQUIRE(!partials_only || (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0 && !fused_merge));
   if (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0) {
     // too few (group, head) chunks to fill the chip: cut the keys over NSPLIT workgroups per chunk as well
     MVT_REQUIRE((uintptr_t)workspace % 16 == 0);
@@ -399,7 +401,7 @@ extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long l
                        q_gs, q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out,
                        workspace, tickets);
 #undef WS
-    if (!fused_merge)
+    if (!fused_merge && !partials_only)
       hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)mvt_cdiv(nchunk, 4)), dim3(256), 0, mvt_stream(stream), workspace, NSPLIT,
                          nchunk, q_gs, q_is, (float*)o, ldo, nq, heads, bf_out);
     return mvt_launch_status();

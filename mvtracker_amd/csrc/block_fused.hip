@@ -67,6 +67,8 @@ struct BlockArgs {
   const unsigned short* ak;
   const unsigned short* av;
   int ldaq, ldakv, S, nkeys, bmv;
+  const float* parts;   // ATT 3: key-split attention partials of mvt_attention_bf16(MVT_ATTN_PARTIALS_ONLY)
+  int nsplit;
 };
 
 __device__ __forceinline__ bf16x8 ldg_frag(const unsigned short* p) {
@@ -459,7 +461,52 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     for (int e = 0; e < 16; ++e) v[mb][e] = 0.f;
 
   // ---- 1. attention output projection (accumulated into v, x is added afterwards)
-  if (MODE != 2 && ATT != 0) {
+  if (MODE != 2 && ATT == 3) {
+    // The attention tile from the key-split partials of the virtual<-point attention (one (m, l, O^T) state per split and
+    // (frame, head) chunk, in attention_mfma_kernel's accumulator layout): the same sequential combination, in the same order,
+    // as attention_merge_kernel -- which this replaces -- so the result is bit-identical.  Contiguous rows; row = token*S + frame.
+    unsigned short* As = &Hs[0][0];
+    const long long nchunk = (long long)p.S * 6;
+    for (int it = t; it < BM * 6 * 12; it += NT) {
+      const int dq = it % 12, hd = (it / 12) % 6, i = it / 72;   // 4 output dims d = 4*dq .. +3 of head hd, tile row i
+      const long long m_ = grow(i);
+      if (m_ < 0) continue;
+      const int tok = (int)(m_ / p.S), fr = (int)(m_ - (long long)tok * p.S);
+      const int mb = tok >> 5, rq = tok & 31;
+      const int d = 4 * dq, db = d >> 5, hh = (d >> 2) & 1, e0 = 4 * ((d & 31) >> 3);
+      const long long cid = (long long)fr * 6 + hd;
+      float mm = 0.f, l0 = 0.f, l1 = 0.f;
+      f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < p.nsplit; ++w) {
+        const float* r0 = p.parts + ((w * nchunk + cid) * 64 + rq) * 68;  // lane (rq, h = 0)
+        const float* r1 = r0 + 32 * 68;                                  // lane (rq, h = 1)
+        const float mw = r0[mb], lw0 = r0[2 + mb], lw1 = r1[2 + mb];
+        const f32x4 ow = *reinterpret_cast<const f32x4*>((hh ? r1 : r0) + 4 + (mb * 2 + db) * 16 + e0);
+        if (w == 0) {
+          mm = mw; l0 = lw0; l1 = lw1; o = ow;
+        } else {
+          const float mn = fmaxf(mm, mw);
+          const float ca = (mm == -INFINITY) ? 0.f : __expf(mm - mn);
+          const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
+          l0 = l0 * ca + lw0 * cb;
+          l1 = l1 * ca + lw1 * cb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o[e] * ca + ow[e] * cb;
+          mm = mn;
+        }
+      }
+      const float inv = 1.0f / (l0 + l1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] *= inv;
+      *reinterpret_cast<u32x2*>(&As[i * LDA + hd * 48 + d]) = __builtin_bit_cast(u32x2, __builtin_convertvector(o, bf16x4));
+    }
+    __syncthreads();
+    gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[mb][e] += p.bo[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+  } else if (MODE != 2 && ATT != 0) {
     unsigned short* As = &Hs[0][0];
     // V^T images of the waves: Xs is idle until the first LayerNorm (NMB 2: all eight fit; NMB 1: four there, two behind As);
     // the zero row (d padding) lives in the LayerNorm scratch, equally idle
@@ -812,8 +859,9 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
                                          const mvt_block_next* next, int n_next, long long M, int Cc, float* workspace, void* stream) {
   MVT_REQUIRE(x && attn && wo && bo && w1 && b1 && w2 && b2 && M > 0 && Cc == C && H > 0 && H % 256 == 0 && H <= 4 * C);
   MVT_REQUIRE(ldx % 4 == 0 && ldx >= C && n_next >= 0 && n_next <= MVT_BLOCK_MAX_NEXT && (n_next == 0 || next));
-  MVT_REQUIRE(attn->q && attn->k && attn->v && attn->heads == 6 && attn->dim_head == DHA && attn->S >= 1 && M % attn->S == 0);
-  MVT_REQUIRE(attn->ldq % 8 == 0 && attn->ldkv % 8 == 0 && attn->ldq >= 288 && attn->ldkv >= 288);
+  MVT_REQUIRE(attn->heads == 6 && attn->dim_head == DHA && attn->S >= 1 && M % attn->S == 0);
+  MVT_REQUIRE(attn->kind == MVT_ATTN_PARTIALS ||
+              (attn->q && attn->k && attn->v && attn->ldq % 8 == 0 && attn->ldkv % 8 == 0 && attn->ldq >= 288 && attn->ldkv >= 288));
   MVT_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)wo % 16 == 0) && ((uintptr_t)w1 % 16 == 0) && ((uintptr_t)w2 % 16 == 0));
   MVT_REQUIRE(((uintptr_t)attn->q % 16 == 0) && ((uintptr_t)attn->k % 16 == 0) && ((uintptr_t)attn->v % 16 == 0));
   BlockArgs a{};
@@ -834,6 +882,17 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
     MVT_REQUIRE(S <= 32 && !workspace);
     a.bmv = (64 / S) * S;
     hipLaunchKernelGGL((block_fused_bf16<2, 0, 1>), dim3((unsigned)mvt_cdiv(M, a.bmv)), dim3(NT), 0, mvt_stream(stream), a);
+  } else if (attn->kind == MVT_ATTN_PARTIALS) {
+    // attention tile from the key-split partials (64 queries = the virtual tokens, frame = group): split path only
+    MVT_REQUIRE(attn->partials && attn->n_splits >= 1 && attn->n_splits <= 8 && attn->n_keys == 64 && M == 64LL * S);
+    MVT_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && M <= 2048 && (uintptr_t)attn->partials % 16 == 0);
+    a.parts = attn->partials; a.nsplit = attn->n_splits;
+    const unsigned tiles = (unsigned)mvt_cdiv(M, 32);
+    hipLaunchKernelGGL((block_fused_bf16<1, 1, 3>), dim3(tiles, (unsigned)(H / 256)), dim3(NT), 0, mvt_stream(stream), a);
+    int maxblk = 1;
+    for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
+    const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
+    hipLaunchKernelGGL((block_fused_bf16<1, 2, 0>), dim3(tiles, slices), dim3(NT), 0, mvt_stream(stream), a);
   } else if (attn->kind == MVT_ATTN_FRAME) {
     MVT_REQUIRE(attn->n_keys >= 1 && attn->n_keys <= 64);
     const long long ntok = M / S;

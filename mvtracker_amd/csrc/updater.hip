@@ -143,11 +143,21 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
     // ---- virtual <- point cross attention, per frame: group = frame (stride 1 row), items stride S rows
     unsigned short* qv = qkv + Mp * ld3;  // q|k|v rows of the virtual tokens
     unsigned short* av = att + Mp * INNER;
+    // the key-split path of mvt_attention_bf16 needs >= 512 keys in 4 x whole 32-key blocks; otherwise the plain form
+    const bool parts = (w->fuse_attention & 16) && n >= 512 && ((n + 31) / 32) % MVT_ATTN_NSPLIT == 0;
     MVT_TRY(mvt_attention_bf16(qv, ld3, 1, S, qkv + INNER, qkv + 2 * INNER, ld3, 1, S, av, INNER, S, NV, n, HEADS, DH_,
-                               BF | ((w->fuse_attention & 8) ? MVT_ATTN_FUSED_MERGE : 0), attn_ws, stream));
+                               BF | (parts ? MVT_ATTN_PARTIALS_ONLY : ((w->fuse_attention & 8) ? MVT_ATTN_FUSED_MERGE : 0)), attn_ws, stream));
     {
       const mvt_block_next nx = next_of(vs.qkv, qv, ld3, 0, 0);
-      MVT_TRY(block(v2p, vt, Mv, av, &nx, 1, split_ws));
+      if (parts) {
+        mvt_block_attn at{};
+        at.kind = MVT_ATTN_PARTIALS; at.S = S; at.n_keys = NV; at.heads = HEADS; at.dim_head = DH_; at.partials = attn_ws;
+        at.n_splits = MVT_ATTN_NSPLIT;
+        MVT_TRY(mvt_attn_block_fused_bf16(vt, H_, &at, v2p.out.w, v2p.out.b, v2p.fc1.w, v2p.fc1.b, v2p.fc2.w, v2p.fc2.b, MLP, &nx, 1, Mv, H_,
+                                          split_ws, stream));
+      } else {
+        MVT_TRY(block(v2p, vt, Mv, av, &nx, 1, split_ws));
+      }
     }
     // ---- virtual self attention, per frame
     {

@@ -486,13 +486,13 @@ ATTN_TIME, ATTN_FRAME = 1, 2
 class BlockAttn(C.Structure):
     """mvt_block_attn."""
     _fields_ = [("kind", C.c_int), ("S", C.c_int), ("n_keys", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int), ("ldq", C.c_int),
-                ("ldkv", C.c_int), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p)]
+                ("ldkv", C.c_int), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("partials", C.c_void_p), ("n_splits", C.c_int)]
 
 
 def attn_block_fused_bf16(x, ldx, kind, S, q, ldq, k, v, ldkv, n_keys, wo, bo, w1, b1, w2, b2, H, nexts, M, Cc, ws=None):
     """``block_fused_bf16`` with the preceding attention inside the kernel (bf16 q / k / v; 6 heads x 48)."""
     assert q.dtype == k.dtype == v.dtype == torch.bfloat16
-    at = BlockAttn(kind, S, n_keys, 6, 48, ldq, ldkv, _ptr(q), _ptr(k), _ptr(v))
+    at = BlockAttn(kind, S, n_keys, 6, 48, ldq, ldkv, _ptr(q), _ptr(k), _ptr(v), None, 0)
     arr = (BlockNext * max(1, len(nexts)))()
     for i, nx in enumerate(nexts):
         arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],

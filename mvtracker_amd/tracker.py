@@ -125,8 +125,9 @@ class MVTracker(nn.Module):
         self.bf16_store = os.environ.get("MVT_BF16_STORE", "1") != "0"  # bf16 mode: bf16 feature rows in the frame store
         # attention inside the block kernels: bit 0 time, bit 1 point<-virtual, bit 2 virtual self; bit 3: in-kernel merge of the
         # key-split virtual<-point attention -- measured 0.8 ms / step SLOWER than the merge launch (release / acquire fences on the
-        # critical path), so off by default (all variants are bit-identical to the separate launches)
-        self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "7"))
+        # critical path), so off by default; bit 4: the virtual<-point block combines the key-split partials in its prologue, no merge
+        # launch (all variants are bit-identical to the separate launches)
+        self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.fuse_head = os.environ.get("MVT_FUSE_HEAD", "1") != "0"  # flow head + track / feature update in one kernel
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
