@@ -217,6 +217,11 @@ int mvt_instnorm_apply(const void* x, const float* mean_rstd, const void* skip, 
  * slice [c_off, c_off+C) of dst [n][Hd][Wd][ldd] (blocks.py:254-280, the 416-channel concat). */
 int mvt_resize_bilinear_ac(const void* src, void* dst, int n, int Hs, int Ws, int C, int Hd, int Wd, int ldd,
                            int c_off, int io_flags /* 0, or IN|OUT: src and dst are bf16 */, void* stream);
+/* The encoder's concat in ONE launch (spatracker/blocks.py:266-276): nsrc <= 4 stage outputs [n][Hs_k][Ws_k][C_k], each resized
+ * like mvt_resize_bilinear_ac, written side by side (channel offsets 0, C_0, C_0 + C_1, ...) into dst [n][Hd][Wd][ldd]; a wave
+ * writes whole contiguous pixel rows.  srcs / Hs / Ws / Cs: HOST arrays.  io_flags: 0 (fp32) or IN_BF16 | OUT_BF16. */
+int mvt_concat_resize_bilinear_ac(int nsrc, const void* const* srcs, const int* Hs, const int* Ws, const int* Cs, void* dst, int n,
+                                  int Hd, int Wd, int ldd, int io_flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Frame store construction (reference: init_pointcloud_from_rgbd, model_utils.py:420-482, and

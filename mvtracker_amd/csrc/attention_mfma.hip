@@ -221,11 +221,11 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
         const float mn = fmaxf(m[mb], mw);
         const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
         const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-        l[mb] = l[mb] * ca + rr[2 + mb] * cb;
+        l[mb] = fmaf(l[mb], ca, rr[2 + mb] * cb);  // (explicit: every merge variant rounds identically)
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = oacc[mb][db][e] * ca + rr[4 + (mb * 2 + db) * 16 + e] * cb;
+          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = fmaf(oacc[mb][db][e], ca, rr[4 + (mb * 2 + db) * 16 + e] * cb);
         m[mb] = mn;
       }
     }
@@ -274,11 +274,11 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
         const float mn = fmaxf(m[mb], mw);
         const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
         const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-        l[mb] = l[mb] * ca + __builtin_nontemporal_load(rw + 2 + mb) * cb;
+        l[mb] = fmaf(l[mb], ca, __builtin_nontemporal_load(rw + 2 + mb) * cb);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = oacc[mb][db][e] * ca + __builtin_nontemporal_load(rw + 4 + (mb * 2 + db) * 16 + e) * cb;
+          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = fmaf(oacc[mb][db][e], ca, __builtin_nontemporal_load(rw + 4 + (mb * 2 + db) * 16 + e) * cb);
         m[mb] = mn;
       }
     }
@@ -341,11 +341,11 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* __res
       const float mn = fmaxf(m[mb], mw);
       const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
       const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-      l[mb] = l[mb] * ca + rr[2 + mb] * cb;
+      l[mb] = fmaf(l[mb], ca, rr[2 + mb] * cb);  // (explicit: every merge variant rounds identically)
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[mb][db][e] = oacc[mb][db][e] * ca + rr[4 + (mb * 2 + db) * 16 + e] * cb;
+        for (int e = 0; e < 16; ++e) oacc[mb][db][e] = fmaf(oacc[mb][db][e], ca, rr[4 + (mb * 2 + db) * 16 + e] * cb);
       m[mb] = mn;
     }
   }

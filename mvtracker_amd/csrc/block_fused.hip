@@ -488,10 +488,10 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
           const float mn = fmaxf(mm, mw);
           const float ca = (mm == -INFINITY) ? 0.f : __expf(mm - mn);
           const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-          l0 = l0 * ca + lw0 * cb;
-          l1 = l1 * ca + lw1 * cb;
+          l0 = fmaf(l0, ca, lw0 * cb);
+          l1 = fmaf(l1, ca, lw1 * cb);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = o[e] * ca + ow[e] * cb;
+          for (int e = 0; e < 4; ++e) o[e] = fmaf(o[e], ca, ow[e] * cb);
           mm = mn;
         }
       }

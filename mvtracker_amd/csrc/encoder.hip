@@ -196,12 +196,86 @@ __global__ void resize_bilinear_ac_kernel(const float* __restrict__ src, float* 
   }
 }
 
+// The encoder's concat (spatracker/blocks.py:266-276): up to four stage outputs, each resized bilinearly (align_corners=True) to
+// the H/4 grid, written side by side into one [n][Hd][Wd][ldd] tensor.  One thread per 16-byte piece of the CONCATENATED pixel
+// row, so a wave writes whole contiguous rows (832 B per pixel at 416 bf16 channels): four separate resize launches each wrote a
+// 128-192-256-byte slice of every row at offsets that are not multiples of the 128-B line.  Same arithmetic as
+// resize_bilinear_ac_kernel.
+struct ConcatSrc {
+  const float* p[4];
+  int Hs[4], Ws[4], C[4], c0[4];  // c0: first output channel of the source
+  int nsrc;
+};
+template <int BF>
+__global__ void concat_resize_kernel(ConcatSrc cs, float* __restrict__ dst, int n, int Hd, int Wd, int ldd) {
+  constexpr int E = BF ? 8 : 4;  // channels per 16-byte piece
+  const int ctot = cs.c0[cs.nsrc - 1] + cs.C[cs.nsrc - 1];
+  const int ppr = ctot / E;      // pieces per pixel row
+  const long long total = (long long)n * Hd * Wd * ppr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int piece = (int)(i % ppr);
+    const long long pix = i / ppr;
+    const int ch = piece * E;
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (k < cs.nsrc && ch >= cs.c0[k]) s = k;
+    const int Hs = cs.Hs[s], Ws = cs.Ws[s], C = cs.C[s];
+    const float* src = cs.p[s];
+    const int x = (int)(pix % Wd);
+    const long long r = pix / Wd;
+    const int y = (int)(r % Hd);
+    const long long img = r / Hd;
+    const float rh = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
+    const float rw = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+    float fy = rh * y, fx = rw * x;
+    int y0 = (int)fy, x0 = (int)fx;
+    int yp = y0 < Hs - 1 ? 1 : 0, xp = x0 < Ws - 1 ? 1 : 0;
+    float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const long long b = ((img * Hs + y0) * (long long)Ws + x0) * C + (ch - cs.c0[s]);
+#pragma unroll
+    for (int hf = 0; hf < E / 4; ++hf) {
+      f32x4 a00 = load_act4(src, b + 4 * hf, BF);
+      f32x4 a01 = load_act4(src, b + (long long)xp * C + 4 * hf, BF);
+      f32x4 a10 = load_act4(src, b + (long long)yp * Ws * C + 4 * hf, BF);
+      f32x4 a11 = load_act4(src, b + ((long long)yp * Ws + xp) * C + 4 * hf, BF);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = hy * (hx * a00[e] + lx * a01[e]) + ly * (hx * a10[e] + lx * a11[e]);
+      store_act4(dst, pix * ldd + ch + 4 * hf, o, BF);
+    }
+  }
+}
+
 inline unsigned grid_for(long long total, int block = 256) {
   long long g = mvt_cdiv(total, block);
   return (unsigned)(g > 256 * 32 ? 256 * 32 : (g < 1 ? 1 : g));
 }
 
 }  // namespace
+
+extern "C" int mvt_concat_resize_bilinear_ac(int nsrc, const void* const* srcs, const int* Hs, const int* Ws, const int* Cs, void* dst,
+                                             int n, int Hd, int Wd, int ldd, int io_flags, void* stream) {
+  MVT_REQUIRE(nsrc >= 1 && nsrc <= 4 && srcs && Hs && Ws && Cs && dst && n > 0 && Hd > 0 && Wd > 0);
+  const int bf = io_flags == (MVT_IO_IN_BF16 | MVT_IO_OUT_BF16);
+  MVT_REQUIRE(io_flags == 0 || bf);
+  const int E = bf ? 8 : 4;
+  ConcatSrc cs{};
+  cs.nsrc = nsrc;
+  int c0 = 0;
+  for (int k = 0; k < nsrc; ++k) {
+    MVT_REQUIRE(srcs[k] && Hs[k] > 0 && Ws[k] > 0 && Cs[k] > 0 && Cs[k] % E == 0 && ((uintptr_t)srcs[k] % 16 == 0));
+    cs.p[k] = (const float*)srcs[k]; cs.Hs[k] = Hs[k]; cs.Ws[k] = Ws[k]; cs.C[k] = Cs[k]; cs.c0[k] = c0;
+    c0 += Cs[k];
+  }
+  MVT_REQUIRE(ldd >= c0 && ldd % E == 0 && ((uintptr_t)dst % 16 == 0));
+  const long long total = (long long)n * Hd * Wd * (c0 / E);
+  if (bf)
+    hipLaunchKernelGGL(concat_resize_kernel<1>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), cs, (float*)dst, n, Hd, Wd, ldd);
+  else
+    hipLaunchKernelGGL(concat_resize_kernel<0>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), cs, (float*)dst, n, Hd, Wd, ldd);
+  return mvt_launch_status();
+}
 
 extern "C" int mvt_rgb_to_nhwc4(const float* rgbs, float* out, int V, int T, int H, int W, int t0, int nt, void* stream) {
   MVT_REQUIRE(rgbs && out && V > 0 && T > 0 && H > 0 && W > 0 && t0 >= 0 && nt > 0 && t0 + nt <= T);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mvt_instnorm_stats": [P, I, P, P, I, LL, I, I, P],
     "mvt_instnorm_apply": [P, P, P, P, P, I, LL, I, I, P],
     "mvt_resize_bilinear_ac": [P, P, I, I, I, I, I, I, I, I, I, P],
+    "mvt_concat_resize_bilinear_ac": [I, P, P, P, P, P, I, I, I, I, I, P],
     "mvt_invert_cameras": [P, P, P, P, I, P],
     "mvt_depth_subsample": [P, P, I, I, I, I, I, P],
     "mvt_avgpool2": [P, P, LL, I, I, I, I, P],
@@ -283,6 +284,15 @@ def instnorm_apply(x, mean_rstd, skip, skip_stats, y, n, HW, Cc, skip_relu=False
 def resize_bilinear_ac(src, dst, n, Hs, Ws, Cc, Hd, Wd, ldd, c_off):
     assert src.dtype == dst.dtype
     _call("mvt_resize_bilinear_ac", _ptr(src), _ptr(dst), n, Hs, Ws, Cc, Hd, Wd, ldd, c_off, _io(src, dst), _stream())
+
+
+def concat_resize_bilinear_ac(srcs, dims, dst, n, Hd, Wd, ldd):
+    """srcs: device tensors (n, Hs_k, Ws_k, C_k) of one element type; dims: [(Hs_k, Ws_k, C_k)]; one launch for the whole concat."""
+    k = len(srcs)
+    assert all(t.dtype == dst.dtype for t in srcs)
+    ia = lambda j: (C.c_int * k)(*[d[j] for d in dims])
+    _call("mvt_concat_resize_bilinear_ac", k, (C.c_void_p * k)(*[_ptr(t) for t in srcs]), ia(0), ia(1), ia(2), _ptr(dst), n, Hd, Wd, ldd,
+          _io(srcs[0], dst), _stream())
 
 
 def invert_cameras(intrs, extrs, kinv, einv, n):

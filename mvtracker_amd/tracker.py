@@ -425,12 +425,16 @@ class MVTracker(nn.Module):
         if not lazy_stem:
             self._inorm(x, n, h * w, 64, st=st)
         cat = torch.empty(n, hs, ws, 416, device=x4.device, dtype=self._act_dtype(pk))
-        cin, off = 64, 0
+        cin = 64
+        stages, dims = [], []
         for li, (cout, stride) in enumerate(((64, 1), (96, 2), (128, 2), (128, 2)), start=1):
             x, h, w = self._res_block(pk, f"fnet.layer{li}.0", x, n, h, w, cin, cout, stride, x_stats=st if (li == 1 and lazy_stem) else None)
             x, h, w = self._res_block(pk, f"fnet.layer{li}.1", x, n, h, w, cout, cout, 1)
-            hip.resize_bilinear_ac(x, cat, n, h, w, cout, hs, ws, 416, off)
-            cin, off = cout, off + cout
+            stages.append(x)
+            dims.append((h, w, cout))
+            cin = cout
+        # the four resized stage outputs side by side (blocks.py:266-276), one launch writing whole 416-channel rows
+        hip.concat_resize_bilinear_ac(stages, dims, cat, n, hs, ws, 416)
         y, _, _, st = self._conv(pk, "fnet.conv2", cat, n, hs, ws, 416, 2 * C, 3, 1, 1, stats=True)
         if self.fuse_norm and self.precision == "bf16" and (2 * C) % 32 == 0:
             # the 1x1 output conv normalises while it loads (row-tile kernel): no separate InstanceNorm pass

@@ -220,6 +220,13 @@ def resize_bilinear_ac(src, dst, n, Hs, Ws, Cc, Hd, Wd, ldd, c_off):
     torch.as_strided(dst, (n, Hd, Wd, Cc), (Hd * Wd * ldd, Wd * ldd, ldd, 1), dst.storage_offset() + c_off).copy_(y.permute(0, 2, 3, 1))
 
 
+def concat_resize_bilinear_ac(srcs, dims, dst, n, Hd, Wd, ldd):
+    off = 0
+    for t, (hs_, ws_, c_) in zip(srcs, dims):
+        resize_bilinear_ac(t, dst, n, hs_, ws_, c_, Hd, Wd, ldd, off)
+        off += c_
+
+
 def invert_cameras(intrs, extrs, kinv, einv, n):
     k = torch.inverse(intrs.reshape(n, 3, 3).double())
     e = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1)
@@ -442,7 +449,7 @@ def install(monkeypatch):
     import sys
     from mvtracker_amd import hip
     me = sys.modules[__name__]
-    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 ln_proj_bf16 mlp_fused_bf16 rgb_to_nhwc4 rgb_images_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac invert_cameras "
+    for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 ln_proj_bf16 mlp_fused_bf16 rgb_to_nhwc4 rgb_images_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac concat_resize_bilinear_ac invert_cameras "
                  "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr window_prepare window_store require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))

@@ -1190,3 +1190,27 @@ def test_metrics_long_clip_and_evaluate_3dpt(hip):
     assert sorted(got) == sorted(ref)
     for k in ref:
         assert (np.isnan(ref[k]) and np.isnan(got[k])) or abs(ref[k] - got[k]) <= 0.011, (k, ref[k], got[k])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_concat_resize_matches_separate_resizes(hip, dt):
+    """One-launch concat (whole 416-channel rows per wave) against the four mvt_resize_bilinear_ac launches it replaces and
+    against torch's F.interpolate(bilinear, align_corners=True)."""
+    g = torch.Generator().manual_seed(2)
+    n, Hd, Wd = 3, 24, 40
+    dims = [(48, 80, 64), (24, 40, 96), (12, 20, 128), (6, 10, 128)]
+    srcs = [torch.randn(n, h, w, c, generator=g).to(dt) for h, w, c in dims]
+    gs = [G(t) for t in srcs]
+    a = torch.zeros(n, Hd, Wd, 416, device=DEV, dtype=dt)
+    b = torch.zeros_like(a)
+    hip.concat_resize_bilinear_ac(gs, dims, a, n, Hd, Wd, 416)
+    off = 0
+    for t, (h, w, c) in zip(gs, dims):
+        hip.resize_bilinear_ac(t, b, n, h, w, c, Hd, Wd, 416, off)
+        off += c
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    ref = torch.cat([F.interpolate(t.float().permute(0, 3, 1, 2), size=(Hd, Wd), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+                     for t in srcs], -1)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert (a.float().cpu() - ref).abs().max().item() < tol
