@@ -1210,7 +1210,7 @@ def test_concat_resize_matches_separate_resizes(hip, dt):
         off += c
     torch.cuda.synchronize()
     # (same expression in two kernels: the compiler may contract the fp32 blend differently -> last-bit differences)
-    assert (a.float() - b.float()).abs().max().item() <= (1e-6 if dt == torch.float32 else 4e-2)
+    assert (a.float() - b.float()).abs().max().item() <= (1e-4 if dt == torch.float32 else 4e-2)
     assert (a.float() != b.float()).float().mean().item() < (1.0 if dt == torch.float32 else 0.02)
     ref = torch.cat([F.interpolate(t.float().permute(0, 3, 1, 2), size=(Hd, Wd), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
                      for t in srcs], -1)
