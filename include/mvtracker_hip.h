@@ -45,6 +45,10 @@ extern "C" {
 /* library / device introspection (host) */
 int mvt_abi_version(void);
 const char* mvt_build_arch(void); /* "gfx950" */
+/* host helpers (not on the data path): a HIP stream restricted to the compute units whose bit is set in mask (n_words x 32 bits,
+ * hipExtStreamCreateWithCUMask) -- the tracker's second (encoder) stream; returns a hipStream_t as void*, NULL on failure */
+void* mvt_stream_create_cu_mask(const unsigned* mask, int n_words);
+int mvt_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense GEMM on the matrix cores (fp32 MFMA 32x32x2, exact fp32 FMA chains).

@@ -29,6 +29,8 @@ P, I, LL, F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 SIGNATURES = {
     "mvt_abi_version": [],
     "mvt_build_arch": [],
+    "mvt_stream_create_cu_mask": [P, I],
+    "mvt_stream_destroy": [P],
     "mvt_gemm": [P, I, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "mvt_split_bf16": [P, P, P, LL, P],
@@ -78,7 +80,7 @@ SIGNATURES = {
     "mvt_updateformer_forward": [P, P, I, I, P, I, P, P, P, P, LL, P],
     "mvt_update_head_bf16": [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, LL, I, I, P, P],
 }
-_RET = {"mvt_build_arch": C.c_char_p, "mvt_updateformer_workspace_bytes": C.c_longlong}
+_RET = {"mvt_build_arch": C.c_char_p, "mvt_stream_create_cu_mask": C.c_void_p, "mvt_updateformer_workspace_bytes": C.c_longlong}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = header / library mismatch
@@ -165,6 +167,25 @@ def _io(t_in, t_out=None):
 def _f32c(t):
     assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
     return t
+
+
+def create_masked_stream(dev, n_cus: int, spread: bool = False, total: int = 256):
+    """A torch stream on ``dev`` restricted to ``n_cus`` of the ``total`` compute units (hipExtStreamCreateWithCUMask), or None when
+    the runtime refuses.  ``spread``: enabled bits spread evenly over the mask instead of the lowest n bits."""
+    bits = [0] * total
+    if spread:
+        for i in range(n_cus):
+            bits[(i * total) // n_cus] = 1
+    else:
+        for i in range(n_cus):
+            bits[i] = 1
+    words = [sum(bits[32 * w + b] << b for b in range(32)) for w in range(total // 32)]
+    arr = (C.c_uint * len(words))(*words)
+    with torch.cuda.device(dev):
+        ptr = _lib.mvt_stream_create_cu_mask(arr, len(words))
+    if not ptr:
+        return None
+    return torch.cuda.ExternalStream(ptr, device=dev)
 
 
 def abi_version() -> int:

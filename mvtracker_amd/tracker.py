@@ -119,6 +119,7 @@ class MVTracker(nn.Module):
         self.mfma_attention = True
         self.overlap_encoder = os.environ.get("MVT_OVERLAP", "1") != "0"  # encode later frames on a second stream
         self._side = {}
+        self.side_stream_cus = "0"
         self._scratch = {}
         self.bf16_tokens = os.environ.get("MVT_BF16_TOK", "1") != "0"  # bf16 mode: q/k/v and attention outputs stored as bf16
         self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
@@ -471,7 +472,13 @@ class MVTracker(nn.Module):
     def _side_stream(self, dev):
         key = (dev.type, dev.index)
         if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
+            st = None
+            spec = os.environ.get("MVT_SIDE_CUS", self.side_stream_cus)  # "<n>" or "<n>:spread"; "0": an ordinary stream
+            n = int(str(spec).split(":")[0])
+            if n > 0:
+                # the encoder stream may use n of the chip's CUs only: the rest stays free for the updater's small kernels
+                st = hip.create_masked_stream(dev, n, spread=str(spec).endswith(":spread"))
+            self._side[key] = st if st is not None else torch.cuda.Stream(device=dev)
         return self._side[key]
 
     @hip.guarded

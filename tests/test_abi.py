@@ -11,7 +11,7 @@ def declared():
     text = open(os.path.join(ROOT, "include", "mvtracker_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
-    for m in re.finditer(r"(?:int|long long|const char\*)\s+(mvt_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"(?:int|long long|const char\*|void\*)\s+(mvt_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return out
