@@ -327,8 +327,9 @@ int mvt_window_corr(const float* fmap, const float* targets, const float* coords
  * 88-106, 134-161).
  * --------------------------------------------------------------------------------------------- */
 /* pos [N][D] = first D entries of the 3x(dim3/3) sin|cos embedding (dim_padded wide) of coords0 (row n at
- * coords[(n*S)*3], fp64 math, omega_j = 10000^(-j/(dim3/6))) (embeddings.py:35-50). */
-int mvt_pos_embed(const float* coords, int N, int S, int D, int dim_padded, float* pos, void* stream);
+ * coords[(n*S)*3], fp64 math, omega_j = 10000^(-j/(dim3/6))) (embeddings.py:35-50).  omega: NULL (computed in the kernel) or a
+ * DEVICE table of dim_padded/6 doubles -- the reference's own numpy values (embeddings.py:95-97). */
+int mvt_pos_embed(const float* coords, int N, int S, int D, int dim_padded, const double* omega, float* pos, void* stream);
 /* x[(n*S+s)*ldx + ..] = cat[flow_embed(coords[n,s]-coords[n,0]) (3*E+3) | fcorr (Fc) |
  * ffeats (C) | mask | vis] + pos[n] + time[s]  (mvtracker.py:379-386). */
 int mvt_token_assemble(const float* coords, const float* fcorr, int Fc, const float* ffeats, int C,

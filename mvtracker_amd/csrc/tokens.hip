@@ -6,7 +6,8 @@ namespace {
 
 // pos[n][d], d < D: per axis a = d / A (A = dim3/3), j = d % A: sin(x_a * w_j) for j < A/2 else
 // cos(x_a * w_{j-A/2}), w_j = 10000^(-j/(A/2)); all in fp64 like the reference's numpy path.
-__global__ void pos_embed_kernel(const float* __restrict__ coords, int N, int S, int D, int dim3, float* __restrict__ pos) {
+__global__ void pos_embed_kernel(const float* __restrict__ coords, int N, int S, int D, int dim3, const double* __restrict__ omega_tab,
+                                 float* __restrict__ pos) {
   const int A = dim3 / 3, half = A / 2;
   const long long total = (long long)N * D;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -14,7 +15,9 @@ __global__ void pos_embed_kernel(const float* __restrict__ coords, int N, int S,
     const long long n = i / D;
     const int a = d / A, j = d - a * A;
     const int jj = j < half ? j : j - half;
-    const double omega = 1.0 / pow(10000.0, (double)jj / ((double)A / 2.0));
+    // omega_j = 10000^(-j / (A/2)): from the caller's table (the reference's numpy values, embeddings.py:95-97; the fp64 pow
+    // per element was most of this kernel's time) or computed here
+    const double omega = omega_tab ? omega_tab[jj] : 1.0 / pow(10000.0, (double)jj / ((double)A / 2.0));
     const double arg = (double)coords[(n * S) * 3 + a] * omega;
     pos[i] = (float)(j < half ? sin(arg) : cos(arg));
   }
@@ -210,9 +213,10 @@ inline unsigned grid_for(long long total) {
 
 }  // namespace
 
-extern "C" int mvt_pos_embed(const float* coords, int N, int S, int D, int dim_padded, float* pos, void* stream) {
+extern "C" int mvt_pos_embed(const float* coords, int N, int S, int D, int dim_padded, const double* omega, float* pos, void* stream) {
   MVT_REQUIRE(coords && pos && N > 0 && S > 0 && D > 0 && dim_padded % 6 == 0 && D <= dim_padded);
-  hipLaunchKernelGGL(pos_embed_kernel, dim3(grid_for((long long)N * D)), dim3(256), 0, mvt_stream(stream), coords, N, S, D, dim_padded, pos);
+  hipLaunchKernelGGL(pos_embed_kernel, dim3(grid_for((long long)N * D)), dim3(256), 0, mvt_stream(stream), coords, N, S, D, dim_padded,
+                     omega, pos);
   return mvt_launch_status();
 }
 

@@ -64,7 +64,7 @@ SIGNATURES = {
     "mvt_corr_gather_dot": [I, P, P, I, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
     "mvt_knn1_gather": [P, I, LL, I, P, I, I, I, P, P, P],
     "mvt_window_corr": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
-    "mvt_pos_embed": [P, I, I, I, I, P, P],
+    "mvt_pos_embed": [P, I, I, I, I, P, P, P],
     "mvt_token_assemble": [P, P, I, P, I, P, P, P, I, I, I, P, I, P],
     "mvt_delta_split": [P, I, P, P, P, P, LL, I, P, P],
     "mvt_rowdot": [P, I, P, P, P, LL, I, P],
@@ -402,8 +402,10 @@ def window_corr(fmap, targets, coords, out, BS, N, Cc, h, w, level, radius, ldo,
           _stream())
 
 
-def pos_embed(coords, N, S, D, dim_padded, pos):
-    _call("mvt_pos_embed", _ptr(coords), N, S, D, dim_padded, _ptr(pos), _stream())
+def pos_embed(coords, N, S, D, dim_padded, pos, omega=None):
+    """omega: optional device fp64 table of dim_padded // 6 frequencies (the reference's numpy values)."""
+    assert omega is None or (omega.dtype == torch.float64 and omega.numel() >= dim_padded // 6)
+    _call("mvt_pos_embed", _ptr(coords), N, S, D, dim_padded, _ptr(omega), _ptr(pos), _stream())
 
 
 def token_assemble(coords, fcorr, Fc, ffeats, Cc, mask_vis, pos, time_embed, N, S, E, x, ldx):

@@ -129,6 +129,7 @@ class MVTracker(nn.Module):
         # critical path), so off by default; bit 4: the virtual<-point block combines the key-split partials in its prologue, no merge
         # launch (all variants are bit-identical to the separate launches)
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
+        self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
         self.fuse_head = os.environ.get("MVT_FUSE_HEAD", "1") != "0"  # flow head + track / feature update in one kernel
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
@@ -287,6 +288,10 @@ class MVTracker(nn.Module):
         lin("ffeats_updater.0")
         pk["vis"] = (sd["vis_predictor.0.weight"].reshape(-1).contiguous(), sd["vis_predictor.0.bias"].contiguous())
         pk["time_embed"] = self._time_embed_host.to(dev)
+        a3 = _round_up(self.updateformer_input_dim, 6) // 3  # embeddings.py:95-97 with embed_dim = dim_padded / 3
+        om = np.arange(a3 // 2, dtype=np.float64)
+        om /= a3 / 2.0
+        pk["pos_omega"] = torch.from_numpy(1.0 / 10000 ** om).to(dev)
         self._packed, self._packed_sig = pk, sig
         return pk
 
@@ -763,9 +768,11 @@ class MVTracker(nn.Module):
         mask_vis = torch.stack([track_mask.float(), vis_init.float()], dim=2).contiguous()
         return self._refine(store, frame0, coords, ffeats, mask_vis, iters, nan_flag, trace)
 
-    def _refine(self, store, frame0, coords, ffeats, mask_vis, iters=4, nan_flag=None, trace=None):
+    def _refine(self, store, frame0, coords, ffeats, mask_vis, iters=4, nan_flag=None, trace=None, carry=None):
         """The refinement loop (mvtracker.py:350-408) on prepared state: coords (n,S,3) and ffeats (n,S,C) are updated IN PLACE,
-        mask_vis (n,S,2) = (track mask, initial visibility logit).  Returns ([coords per traced iteration ..., final], vis)."""
+        mask_vis (n,S,2) = (track mask, initial visibility logit).  Returns ([coords per traced iteration ..., final], vis).
+        ``carry`` = (neighbour indices (L,n_prev,S,K) of the previous window's last iteration, p0): the first p0 tracks continue
+        from that window, so its neighbours seed (bound) this window's first exact scan.  ``self._last_idx`` holds this window's."""
         S, C, K, L, E = self.S, self.latent_dim, self.corr_neighbors, self.corr_n_levels, self.flow_embed_dim
         n = coords.shape[0]
         dev = coords.device
@@ -774,7 +781,7 @@ class MVTracker(nn.Module):
         T = store["T"]
         Fc = L * K * 4
         pos = torch.empty(n, D, device=dev)
-        hip.pos_embed(coords, n, S, D, _round_up(D, 6), pos)
+        hip.pos_embed(coords, n, S, D, _round_up(D, 6), pos, pk["pos_omega"])
         fcorr = torch.empty(n, S, Fc, device=dev)
         ldx = _round_up(D, 4)
         x = torch.empty(n * S, ldx, device=dev)      # (token_assemble writes the pad columns as zeros)
@@ -795,14 +802,30 @@ class MVTracker(nn.Module):
                 hip.knn_scan_levels(levels, coords, n, S, frame0, 1, T, K, seed_k=K)
                 hip.knn_merge_levels(levels, n, S, K)
             else:
-                for lvl in reversed(range(L)):  # coarse to fine: level l+1's neighbours bound level l's first scan
-                    P = store["P"][lvl]
-                    seed = {}
-                    if lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
-                        seed = dict(seed_idx=idx[lvl + 1], seed_k=K, seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
-                    hip.knn_scan(store["xyz"][lvl], P, coords, n, S, frame0, 1, T, K, nsegs[lvl], keys[lvl], box=store["box"][lvl],
-                                 grid=store["tile_grid"][lvl], **seed)
-                    hip.knn_merge(keys[lvl], n, S, K, nsegs[lvl], P, idx[lvl])
+                n0 = 0
+                if carry is not None and carry[1] > 0 and self.seed_across_windows:
+                    # Tracks carried over from the previous window (mvtracker.py:648-651 start them at its last estimates): that
+                    # window's final neighbours -- slot s continues slot s + S/2, the last slot held -- are K distinct points of
+                    # every frame's cloud (same pixel grid), i.e. an exact upper bound of the K-th distance, and a tight one; all
+                    # four levels in one seeded launch instead of four coarse-to-fine scans.  Exactness is unaffected.
+                    prev_idx, n0 = carry
+                    slot = torch.tensor([min(s_ + S // 2, S - 1) for s_ in range(S)], device=dev)
+                    seed_t = prev_idx[:, :n0].index_select(2, slot).contiguous()
+                    lv0 = [dict(lv, keys=keys[l_][:n0 * S * nsegs[l_] * K], seed_idx=seed_t[l_], idx_out=idx[l_][:n0]) for l_, lv in enumerate(levels)]
+                    hip.knn_scan_levels(lv0, coords, n0, S, frame0, 1, T, K, seed_k=K)
+                    hip.knn_merge_levels(lv0, n0, S, K)
+                if n0 < n:  # new tracks: coarse to fine, level l+1's neighbours bound level l's first scan
+                    m = n - n0
+                    for lvl in reversed(range(L)):
+                        P = store["P"][lvl]
+                        seed = {}
+                        if lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
+                            seed = dict(seed_idx=idx[lvl + 1][n0:], seed_k=K,
+                                        seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
+                        kl = keys[lvl][n0 * S * nsegs[lvl] * K:]
+                        hip.knn_scan(store["xyz"][lvl], P, coords[n0:], m, S, frame0, 1, T, K, nsegs[lvl], kl, box=store["box"][lvl],
+                                     grid=store["tile_grid"][lvl], **seed)
+                        hip.knn_merge(kl, m, S, K, nsegs[lvl], P, idx[lvl][n0:])
             hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0, 1,
                                 T, K, fcorr, Fc, 0)
             hip.token_assemble(coords, fcorr, Fc, ffeats, C, mask_vis, pos, pk["time_embed"], n, S, E, x, ldx)
@@ -825,6 +848,7 @@ class MVTracker(nn.Module):
         hip.rowdot(ffeats, C, *pk["vis"], vis, n * S, C)
         if trace is not None:
             trace["ffeats"] = ffeats
+        self._last_idx = idx
         return preds, vis
 
     # ------------------------------------------------------------------ forward (mvtracker.py:412-732)
@@ -908,7 +932,7 @@ class MVTracker(nn.Module):
                         ev.record(side)
                         pending.append((a, ev))
         p0 = 0
-        coords = vis = None
+        coords = vis = prev_idx = None
         while w < T - S // 2:  # mvtracker.py:537
             p1 = int(np.searchsorted(qt_s, w + S, side="left"))  # number of queries with t < w+S (:538-540)
             assert p1 > 0
@@ -937,7 +961,9 @@ class MVTracker(nn.Module):
             if trace is not None:
                 wtrace = {}
                 trace.append(wtrace)
-            preds, vis = self._refine(store, w, wc, wf, wm, iters=iters, nan_flag=nan_flag, trace=wtrace)
+            preds, vis = self._refine(store, w, wc, wf, wm, iters=iters, nan_flag=nan_flag, trace=wtrace,
+                                      carry=(prev_idx, p0) if p0 > 0 else None)
+            prev_idx = self._last_idx
             coords = preds[-1]
             hip.window_store(coords, vis, order_d, p1, S, w, T, N, traj, vis_logit, vis_prob)  # :692-693, un-sorted (:710-711)
             windows.append((w, p1))

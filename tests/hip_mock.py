@@ -342,7 +342,7 @@ def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):
         idx_out.reshape(n).copy_(idx.int())
 
 
-def pos_embed(coords, N, S, D, dim_padded, pos):
+def pos_embed(coords, N, S, D, dim_padded, pos, omega=None):
     import numpy as np
     A = dim_padded // 3
     omega = 1.0 / 10000 ** (np.arange(A // 2, dtype=np.float64) / (A / 2.0))
