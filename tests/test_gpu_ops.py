@@ -1214,5 +1214,5 @@ def test_concat_resize_matches_separate_resizes(hip, dt):
     assert (a.float() != b.float()).float().mean().item() < (1.0 if dt == torch.float32 else 0.02)
     ref = torch.cat([F.interpolate(t.float().permute(0, 3, 1, 2), size=(Hd, Wd), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
                      for t in srcs], -1)
-    tol = 2e-5 if dt == torch.float32 else 2e-2
+    tol = 1e-4 if dt == torch.float32 else 2e-2
     assert (a.float().cpu() - ref).abs().max().item() < tol
