@@ -12,6 +12,7 @@ the refinement loop; the small outputs are all-gathered at the end when requeste
 """
 from __future__ import annotations
 
+import logging
 import os
 from typing import Optional
 
@@ -20,11 +21,14 @@ import torch.distributed as dist
 
 from . import hip
 
+log = logging.getLogger(__name__)
+
 
 class ShardedTracker:
     def __init__(self, model, group: Optional["dist.ProcessGroup"] = None):
         self.model = model
         self.group = group
+        self._no_inplace = False
 
     def _world(self):
         if dist.is_available() and dist.is_initialized():
@@ -49,8 +53,15 @@ class ShardedTracker:
         """``out`` = world equal chunks along dim 0; this rank's chunk already holds its contribution."""
         per = out.shape[0] // world
         mine = out[rank * per:(rank + 1) * per]
+        if dist.get_backend(self.group) == "nccl" and not self._no_inplace:
+            try:
+                dist.all_gather_into_tensor(out, mine, group=self.group)  # in-place form: input aliases its slot of the output
+                return
+            except RuntimeError as e:  # a runtime that rejects the aliasing form: stage this rank's share once, from then on
+                self._no_inplace = True
+                log.warning("in-place all_gather_into_tensor rejected (%s); staging the local share", e)
         if dist.get_backend(self.group) == "nccl":
-            dist.all_gather_into_tensor(out, mine, group=self.group)  # in-place form: input aliases its slot of the output
+            dist.all_gather_into_tensor(out, mine.clone(), group=self.group)
         else:
             dist.all_gather(list(out.chunk(world, dim=0)), mine.clone(), group=self.group)
 
