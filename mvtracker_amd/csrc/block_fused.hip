@@ -417,12 +417,13 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
   static_assert(ATT == 0 || MODE != 2, "pass 2 of the split path has no attention");
+  constexpr bool FM = ATT == 2 || ATT == 3;                    // frame-major tile: tokens blockIdx.x*BM.. of frame blockIdx.z
   const int bmv = ATT == 1 ? p.bmv : BM;                      // rows of the tile that hold tokens
-  const long long m0 = ATT == 2 ? 0 : (long long)blockIdx.x * bmv;
-  const long long ntok = ATT == 2 ? p.M / p.S : 0;             // ATT 2: tokens per frame
+  const long long m0 = FM ? 0 : (long long)blockIdx.x * bmv;
+  const long long ntok = FM ? p.M / p.S : 0;                   // tokens per frame
   // global row of tile row i (-1: none)
   auto grow = [&](int i) -> long long {
-    if (ATT == 2) {
+    if (FM) {
       const long long tk = (long long)blockIdx.x * BM + i;
       return tk < ntok ? tk * p.S + (long long)blockIdx.z : -1;
     }
@@ -430,8 +431,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     return (i < bmv && m < p.M) ? m : -1;
   };
   // rows [rlo, rhi) bound the tile (workgroup-uniform)
-  const long long rlo = ATT == 2 ? (long long)blockIdx.x * BM * p.S : m0;
-  const long long rhi = ATT == 2 ? ((long long)blockIdx.x * BM + BM) * p.S : m0 + bmv;
+  const long long rlo = FM ? (long long)blockIdx.x * BM * p.S : m0;
+  const long long rhi = FM ? ((long long)blockIdx.x * BM + BM) * p.S : m0 + bmv;
   if (MODE != 2)
     for (int i = t; i < p.H; i += NT) b1s[i] = p.b1[i];
   const long long MC = p.M * (long long)C;
@@ -463,42 +464,57 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   // ---- 1. attention output projection (accumulated into v, x is added afterwards)
   if (MODE != 2 && ATT == 3) {
     // The attention tile from the key-split partials of the virtual<-point attention (one (m, l, O^T) state per split and
-    // (frame, head) chunk, in attention_mfma_kernel's accumulator layout): the same sequential combination, in the same order,
-    // as attention_merge_kernel -- which this replaces -- so the result is bit-identical.  Contiguous rows; row = token*S + frame.
+    // (frame, head) chunk, in attention_mfma_kernel's accumulator layout).  The tile is frame-major -- the 32 virtual tokens
+    // mb = blockIdx.x of frame blockIdx.z -- so wave hd reads the records of its (frame, head) chunk in their NATIVE lane layout
+    // (lane (r, h): query mb*32 + r, rows d = db*32 + (e&3) + 8(e>>2) + 4h) and combines the splits with the same sequential
+    // arithmetic, in the same order, as attention_merge_kernel -- which this replaces: bit-identical results.
     unsigned short* As = &Hs[0][0];
-    const long long nchunk = (long long)p.S * 6;
-    for (int it = t; it < BM * 6 * 12; it += NT) {
-      const int dq = it % 12, hd = (it / 12) % 6, i = it / 72;   // 4 output dims d = 4*dq .. +3 of head hd, tile row i
-      const long long m_ = grow(i);
-      if (m_ < 0) continue;
-      const int tok = (int)(m_ / p.S), fr = (int)(m_ - (long long)tok * p.S);
-      const int mb = tok >> 5, rq = tok & 31;
-      const int d = 4 * dq, db = d >> 5, hh = (d >> 2) & 1, e0 = 4 * ((d & 31) >> 3);
-      const long long cid = (long long)fr * 6 + hd;
-      float mm = 0.f, l0 = 0.f, l1 = 0.f;
-      f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int w = 0; w < p.nsplit; ++w) {
-        const float* r0 = p.parts + ((w * nchunk + cid) * 64 + rq) * 68;  // lane (rq, h = 0)
-        const float* r1 = r0 + 32 * 68;                                  // lane (rq, h = 1)
-        const float mw = r0[mb], lw0 = r0[2 + mb], lw1 = r1[2 + mb];
-        const f32x4 ow = *reinterpret_cast<const f32x4*>((hh ? r1 : r0) + 4 + (mb * 2 + db) * 16 + e0);
-        if (w == 0) {
-          mm = mw; l0 = lw0; l1 = lw1; o = ow;
-        } else {
-          const float mn = fmaxf(mm, mw);
-          const float ca = (mm == -INFINITY) ? 0.f : __expf(mm - mn);
-          const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-          l0 = fmaf(l0, ca, lw0 * cb);
-          l1 = fmaf(l1, ca, lw1 * cb);
+    static_assert(ATT != 3 || NMB == 1, "partials tiles are 32 tokens");
+    if (wave < 6) {
+      const int mb = (int)blockIdx.x;
+      const long long nchunk = (long long)p.S * 6;
+      const long long cid = (long long)blockIdx.z * 6 + wave;
+      const float* r0 = p.parts + (cid * 64 + lane) * 68;
+      float mm = r0[mb], ll = r0[2 + mb];
+      f32x16 oa[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaf(o[e], ca, ow[e] * cb);
-          mm = mn;
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 q4 = *reinterpret_cast<const f32x4*>(r0 + 4 + (mb * 2 + db) * 16 + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) oa[db][4 * g + e] = q4[e];
         }
-      }
-      const float inv = 1.0f / (l0 + l1);
+      for (int w = 1; w < p.nsplit; ++w) {
+        const float* rw = p.parts + ((w * nchunk + cid) * 64 + lane) * 68;
+        const float mw = rw[mb];
+        const float mn = fmaxf(mm, mw);
+        const float ca = (mm == -INFINITY) ? 0.f : __expf(mm - mn);
+        const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
+        ll = fmaf(ll, ca, rw[2 + mb] * cb);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] *= inv;
-      *reinterpret_cast<u32x2*>(&As[i * LDA + hd * 48 + d]) = __builtin_bit_cast(u32x2, __builtin_convertvector(o, bf16x4));
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(rw + 4 + (mb * 2 + db) * 16 + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oa[db][4 * g + e] = fmaf(oa[db][4 * g + e], ca, q4[e] * cb);
+          }
+        mm = mn;
+      }
+      const float inv = 1.0f / (ll + __shfl_xor(ll, 32, 64));
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * h;
+          if (d < DHA) {
+            f32x4 t4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t4[e] = oa[db][4 * g + e] * inv;
+            *reinterpret_cast<u32x2*>(&As[r * LDA + wave * DHA + d]) = __builtin_bit_cast(u32x2, __builtin_convertvector(t4, bf16x4));
+          }
+        }
     }
     __syncthreads();
     gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);
@@ -888,7 +904,8 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
     MVT_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && M <= 2048 && (uintptr_t)attn->partials % 16 == 0);
     a.parts = attn->partials; a.nsplit = attn->n_splits;
     const unsigned tiles = (unsigned)mvt_cdiv(M, 32);
-    hipLaunchKernelGGL((block_fused_bf16<1, 1, 3>), dim3(tiles, (unsigned)(H / 256)), dim3(NT), 0, mvt_stream(stream), a);
+    a.S = S;
+    hipLaunchKernelGGL((block_fused_bf16<1, 1, 3>), dim3(2, (unsigned)(H / 256), (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
     int maxblk = 1;
     for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
     const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
