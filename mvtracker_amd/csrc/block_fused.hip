@@ -433,7 +433,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   // rows [rlo, rhi) bound the tile (workgroup-uniform)
   const long long rlo = FM ? (long long)blockIdx.x * BM * p.S : m0;
   const long long rhi = FM ? ((long long)blockIdx.x * BM + BM) * p.S : m0 + bmv;
-  if (MODE != 2)
+  constexpr bool HAS_MLP = MODE == 0 || MODE == 1;  // MODE 2: pass 2 of the split path; MODE 3: LayerNorm + projections of a
+                                                    // read-only x in whole 64-row tiles (mvt_ln_proj_bf16 at large M)
+  if (HAS_MLP)
     for (int i = t; i < p.H; i += NT) b1s[i] = p.b1[i];
   const long long MC = p.M * (long long)C;
   // a projection runs in this workgroup when its row range meets the workgroup's rows (workgroup-uniform)
@@ -640,9 +642,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
     }
   };
-  if (MODE != 2) ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
+  if (HAS_MLP) ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
   const bool tail_next = MODE == 0 && active(0) && wave < (p.next[0].N + 31) / 32;
-  if (MODE != 2) {
+  if (HAS_MLP) {
     f32x16 acc2[NMB];
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     // after this wave's last block the queue moves on to its first block of the next projection, if that one runs here
     const int qn = q + 1 < MVT_BLOCK_MAX_NEXT ? q + 1 : MVT_BLOCK_MAX_NEXT - 1;
     const unsigned short* chain = nullptr;
-    if (MODE == 0 && q + 1 < MVT_BLOCK_MAX_NEXT && active(q + 1) && wave < (p.next[qn].N + 31) / 32)
+    if ((MODE == 0 || MODE == 3) && q + 1 < MVT_BLOCK_MAX_NEXT && active(q + 1) && wave < (p.next[qn].N + 31) / 32)
       chain = p.next[qn].w + ((long long)wave * (C / 16) * 64 + lane) * 8;
     have = chain != nullptr && wave < nblocks;
     for (int nb = nb0; nb < nblocks; nb += nbstep) {
@@ -950,7 +952,10 @@ extern "C" int mvt_ln_proj_bf16(const float* x, int ldx, const mvt_block_next* n
     if (nx.row_hi == 0) a.next[q].row_hi = M;
     maxblk = (nx.N + 31) / 32 > maxblk ? (nx.N + 31) / 32 : maxblk;
   }
-  hipLaunchKernelGGL((block_fused_bf16<1, 2, 0>), dim3((unsigned)mvt_cdiv(M, 32), (unsigned)mvt_cdiv(maxblk, 8)), dim3(NT), 0, mvt_stream(stream),
-                     a);
+  if (M >= 4096)  // whole 64-row tiles, every column block in the workgroup: x and its LayerNorm are read / computed once per tile
+    hipLaunchKernelGGL((block_fused_bf16<2, 3, 0>), dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
+  else
+    hipLaunchKernelGGL((block_fused_bf16<1, 2, 0>), dim3((unsigned)mvt_cdiv(M, 32), (unsigned)mvt_cdiv(maxblk, 8)), dim3(NT), 0,
+                       mvt_stream(stream), a);
   return mvt_launch_status();
 }
