@@ -103,6 +103,8 @@ int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const uns
  *                   in out_partial are taken before the rounding) */
 #define MVT_IO_IN_BF16 1
 #define MVT_IO_OUT_BF16 2
+#define MVT_IO_BACKGROUND 16 /* mvt_conv2d_bf16: launch at reduced occupancy (one workgroup per CU): work on a second stream
+                                that should leave the chip's CUs mostly to the caller's main stream */
 int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad, int split /* wt_lo != NULL */);
 int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
                     void* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,

@@ -219,10 +219,13 @@ def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False) -> int:
     return _lib.mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, int(split))
 
 
+IO_BACKGROUND = 16
+
+
 def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE, in_stats=None,
-                out_partial=None):
+                out_partial=None, background=False):
     _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
-          ldo, act, _io(x, out), _ptr(in_stats), _ptr(out_partial), _stream())
+          ldo, act, _io(x, out) | (IO_BACKGROUND if background else 0), _ptr(in_stats), _ptr(out_partial), _stream())
 
 
 def instnorm_finish_slots(partial, slots, mean_rstd, n, HW, Cc):

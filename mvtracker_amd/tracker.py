@@ -119,6 +119,8 @@ class MVTracker(nn.Module):
         self.mfma_attention = True
         self.overlap_encoder = os.environ.get("MVT_OVERLAP", "1") != "0"  # encode later frames on a second stream
         self._side = {}
+        self._background = False
+        self.background_encoder = os.environ.get("MVT_BG_ENCODER", "0") != "0"  # side-stream convs at one workgroup per CU
         self.side_stream_cus = "0"
         self._scratch = {}
         self.bf16_tokens = os.environ.get("MVT_BF16_TOK", "1") != "0"  # bf16 mode: q/k/v and attention outputs stored as bf16
@@ -375,7 +377,8 @@ class MVTracker(nn.Module):
         if isinstance(wt, tuple):
             slots = hip.conv2d_stat_slots(H, W, cin, k, k, stride, pad, wt[1] is not None) if (stats and self.fuse_norm) else 0
             part = torch.empty(n * slots * cout * 2, device=x.device) if slots else None
-            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo, in_stats=in_stats, out_partial=part)
+            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo, in_stats=in_stats, out_partial=part,
+                            background=self._background)
             if slots:
                 st = torch.empty(n, cout, 2, device=x.device)
                 hip.instnorm_finish_slots(part, slots, st, n, Ho * Wo, cout)
@@ -926,11 +929,15 @@ class MVTracker(nn.Module):
                 side = self._side_stream(dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    for a in range(ready, T, S // 2):
-                        self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
-                        ev = torch.cuda.Event()
-                        ev.record(side)
-                        pending.append((a, ev))
+                    self._background = self.background_encoder
+                    try:
+                        for a in range(ready, T, S // 2):
+                            self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            pending.append((a, ev))
+                    finally:
+                        self._background = False
         p0 = 0
         coords = vis = prev_idx = None
         while w < T - S // 2:  # mvtracker.py:537
