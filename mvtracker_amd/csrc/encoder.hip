@@ -105,15 +105,17 @@ __global__ void instnorm_finish_kernel(const double* __restrict__ partial, float
   mean_rstd[i * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
 }
 
-// block (channel group of 16, image): 64 slot lanes x 16 channels accumulate in fp64, fixed-order LDS reduction
+// block (channel group of FC, image): 1024 / FC slot lanes x FC channels accumulate in fp64, fixed-order LDS reduction (deterministic).
+// FC = 8: twice the workgroups of the first version (16 channels) -- at 64 channels x 24 images that one ran on 96 workgroups only.
+constexpr int FC = 8, FL = 1024 / FC;
 __global__ __launch_bounds__(1024) void instnorm_finish_slots_kernel(const float* __restrict__ partial, int slots,
                                                                      float* __restrict__ mean_rstd, long long HW, int C) {
   __shared__ double red[1024 * 2];
-  const int t = threadIdx.x, c = blockIdx.x * 16 + (t & 15), l = t >> 4;
+  const int t = threadIdx.x, c = blockIdx.x * FC + (t % FC), l = t / FC;
   const long long img = blockIdx.y;
   double s = 0, ss = 0;
   if (c < C) {
-    for (int sl = l; sl < slots; sl += 64) {
+    for (int sl = l; sl < slots; sl += FL) {
       const float2 v = *reinterpret_cast<const float2*>(partial + ((img * slots + sl) * C + c) * 2);
       s += (double)v.x;
       ss += (double)v.y;
@@ -122,12 +124,16 @@ __global__ __launch_bounds__(1024) void instnorm_finish_slots_kernel(const float
   red[t * 2] = s;
   red[t * 2 + 1] = ss;
   __syncthreads();
-  if (t < 16 && c < C) {
-    s = 0, ss = 0;
-    for (int k = 0; k < 64; ++k) {
-      s += red[(k * 16 + t) * 2];
-      ss += red[(k * 16 + t) * 2 + 1];
+  // tree over the slot lanes in a fixed order (pairs at distance 64, 32, ... lanes): deterministic
+  for (int w = FL / 2; w >= 1; w >>= 1) {
+    if (l < w) {
+      red[t * 2] += red[(t + w * FC) * 2];
+      red[t * 2 + 1] += red[(t + w * FC) * 2 + 1];
     }
+    __syncthreads();
+  }
+  if (t < FC && c < C) {
+    s = red[t * 2], ss = red[t * 2 + 1];
     double mean = s / (double)HW;
     double var = ss / (double)HW - mean * mean;
     if (var < 0) var = 0;
@@ -334,7 +340,7 @@ extern "C" int mvt_instnorm_stats(const void* x, int ldx, double* partial, float
 
 extern "C" int mvt_instnorm_finish_slots(const float* partial, int slots, float* mean_rstd, int n, long long HW, int C, void* stream) {
   MVT_REQUIRE(partial && mean_rstd && slots > 0 && n > 0 && HW > 0 && C > 0);
-  hipLaunchKernelGGL(instnorm_finish_slots_kernel, dim3((unsigned)mvt_cdiv(C, 16), (unsigned)n), dim3(1024), 0, mvt_stream(stream),
+  hipLaunchKernelGGL(instnorm_finish_slots_kernel, dim3((unsigned)mvt_cdiv(C, FC), (unsigned)n), dim3(1024), 0, mvt_stream(stream),
                      partial, slots, mean_rstd, HW, C);
   return mvt_launch_status();
 }
