@@ -45,9 +45,13 @@ constexpr int MAXC = 512;        // input channels the in-kernel normalisation s
 // Elements of the per-wave LDS staging tile of the bf16 epilogue: 32 pixels x (BN + 8) channels
 template <int TN> constexpr int stage_elems() { return 32 * (TN * 32 + 8); }
 
+// Statistics: every (tile row, channel) leaves its (sum, sum of squares) over the row's 32 pixels in the workgroup's LDS table
+// wst[tile row][BN][2] (pre-zeroed; lrow0 = first tile row of this wave); the kernel adds the rows up in a fixed order and writes
+// ONE slot per workgroup (tile) -- eight times fewer partials to write and to reduce than one slot per row segment.
 template <int TM, int TN, bool QUADS, bool STAGED>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const RowsArgs& p, long long img, int Ho, int Wo, int yw, int x0,
-                                              int n0, int tiles_x, int tx, int lane, unsigned short* stage) {
+                                              int n0, int tiles_x, int tx, int lane, unsigned short* stage, float* wst, int lrow0) {
+  constexpr int BNS = TN * 32;
   const int r = lane & 31, h = lane >> 5;
   if (STAGED) {  // (compile-time: with both paths in one kernel the accumulators are copied out ahead of the branch -> +50 VGPRs)
     // bf16 output through LDS: the accumulator layout (channel on the lane, 16 pixels in the registers) would store 2-4 bytes
@@ -76,11 +80,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
           }
           if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four accumulator registers at a time (VGPR budget)
         }
-        if (p.out_part) {  // one writer per (row segment, channel): deterministic
+        if (p.out_part) {  // one writer per (tile row, channel): deterministic
           s1 += __shfl_xor(s1, 32, 64);
           s2 += __shfl_xor(s2, 32, 64);
           if (h == 0 && nok) {
-            float* pp = p.out_part + ((img * p.slots + (long long)y * tiles_x + tx) * p.Cout + n) * 2;
+            float* pp = wst + ((lrow0 + i) * BNS + j * 32 + r) * 2;
             pp[0] = s1;
             pp[1] = s2;
           }
@@ -200,16 +204,32 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
           }
         }
       }
-      if (p.out_part) {  // one writer per (row segment, channel): deterministic
+      if (p.out_part) {  // one writer per (tile row, channel): deterministic
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (h == 0 && nok) {
-          float* pp = p.out_part + ((img * p.slots + (long long)y * tiles_x + tx) * p.Cout + n) * 2;
+          float* pp = wst + ((lrow0 + i) * BNS + j * 32 + r) * 2;
           pp[0] = s1;
           pp[1] = s2;
         }
       }
     }
+  }
+}
+
+// After the epilogue (and a barrier): channel c of the tile = sum of its rows' entries in row order -> the workgroup's slot.
+template <int ROWS, int BN>
+__device__ __forceinline__ void write_tile_stats(const RowsArgs& p, const float* wst, long long img, int tile, int n0, int t) {
+  if (p.out_part && t < BN && n0 + t < p.Cout) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      s1 += wst[(rr * BN + t) * 2];
+      s2 += wst[(rr * BN + t) * 2 + 1];
+    }
+    float* pp = p.out_part + ((img * p.slots + tile) * p.Cout + n0 + t) * 2;
+    pp[0] = s1;
+    pp[1] = s2;
   }
 }
 
@@ -244,6 +264,7 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
   __shared__ __attribute__((aligned(16))) unsigned short Ws[KS * BN * LDP];
   static_assert(!STAGED || NW * stage_elems<TN>() <= G::NSLOT * LDP, "the bf16 epilogue's staging tiles reuse the patch LDS");
   __shared__ __attribute__((aligned(16))) float Sst[2 * MAXC];  // (mean, rstd) of the input channels of this image
+  __shared__ float wst[G::ROWS * BN * 2];                       // per (tile row, channel) output statistics
 
   const int t = threadIdx.x;
   const int Ho = (p.H + 2 * G::PAD - KS) / S + 1, Wo = (p.W + 2 * G::PAD - KS) / S + 1;
@@ -377,6 +398,7 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  for (int i = t; i < G::ROWS * BN * 2; i += NT) wst[i] = 0.f;  // (rows past the image stay zero; the loop's barriers order this)
   const int nchunk = p.Cin / CK;
   load_patch(0);
   load_w(0, 0);
@@ -421,7 +443,12 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
   // same channels of pixel e+1 -- one 4-byte (bf16) / 8-byte (fp32) store per lane and register PAIR instead of a 2-byte
   // store per register (the scalar bf16 stores alone were a third of the 64-channel layers' time).
   // (the loop above ended with a barrier: patch and weights are dead, the staging tiles reuse their LDS)
-  epilogue_rows<TM, TN, TN == 3, STAGED>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, n0, tiles_x, tx, lane, Ps + wm * stage_elems<TN>());
+  epilogue_rows<TM, TN, TN == 3, STAGED>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, n0, tiles_x, tx, lane, Ps + wm * stage_elems<TN>(), wst,
+                                         wm * TM);
+  if (p.out_part) {
+    __syncthreads();
+    write_tile_stats<G::ROWS, BN>(p, wst, img, ty * tiles_x + tx, n0, t);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -443,7 +470,9 @@ __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
   constexpr int NWF = (BN * (SKW / 8) + 255) / 256;
   __shared__ __attribute__((aligned(16))) unsigned short Ps[SNP * 4];
   __shared__ __attribute__((aligned(16))) unsigned short Ws[BN * SLW];
+  __shared__ float wst[TR * BN * 2];
   const int t = threadIdx.x;
+  for (int i = t; i < TR * BN * 2; i += 256) wst[i] = 0.f;
   const int Ho = (p.H + 6 - 7) / 2 + 1, Wo = (p.W + 6 - 7) / 2 + 1;
   const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + TR - 1) / TR;
   int b = blockIdx.x;
@@ -515,13 +544,30 @@ __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
 
   __syncthreads();  // every wave is done with the patch / weights: Ws becomes the staging area
   static_assert(4 * stage_elems<TN>() <= BN * SLW, "staging tiles fit the weight buffer");
-  epilogue_rows<TM, TN, true, STAGED>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, 0, tiles_x, tx, lane, Ws + wm * stage_elems<TN>());
+  epilogue_rows<TM, TN, true, STAGED>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, 0, tiles_x, tx, lane, Ws + wm * stage_elems<TN>(), wst, wm * TM);
+  if (p.out_part) {
+    __syncthreads();
+    write_tile_stats<TR, BN>(p, wst, img, ty * tiles_x + tx, 0, t);
+  }
 }
 
 }  // namespace
 
-// slots of the fused statistics: one per 32-pixel row segment
-__attribute__((visibility("hidden"))) int mvt_detail_conv_rows_slots(int H, int W) { return H * (int)mvt_cdiv(W, TC); }
+// tile rows of the variant the launcher picks for (kernel size, stride) -- shared with mvt_conv2d_stat_slots
+static int rows_nw8() {
+  static const int v = getenv("MVT_ROWS_NW8") ? atoi(getenv("MVT_ROWS_NW8")) : 0;  // tuning override
+  return v;
+}
+__attribute__((visibility("hidden"))) int mvt_detail_conv_rows_tile_rows(int ksize, int stride, int Ho) {
+  if (ksize == 3 && stride == 1) return (rows_nw8() == 1 && Ho % 16 == 0) ? 16 : (rows_nw8() == 2 ? 4 : 8);
+  if (ksize == 3) return 4;
+  if (ksize == 7) return TR;  // stem
+  return 8;
+}
+// slots of the fused statistics: one per workgroup tile (tile rows x 32 output pixels)
+__attribute__((visibility("hidden"))) int mvt_detail_conv_rows_slots(int Ho, int Wo, int tile_rows) {
+  return (int)(mvt_cdiv(Ho, tile_rows) * mvt_cdiv(Wo, TC));
+}
 
 // 3x3 (pad 1) or 1x1 (pad 0) convolution, stride 1 or 2, Cin % 32 == 0, bf16 mode
 __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, const unsigned short* w, int ldw, const float* bias, void* out,
@@ -536,7 +582,7 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
   RowsArgs a{};
   a.in = (const float*)in; a.w = w; a.bias = bias; a.out = (float*)out; a.in_stats = in_stats; a.out_part = out_partial;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldw = ldw; a.ldo = ldo;
-  a.slots = mvt_detail_conv_rows_slots(Ho, Wo);
+  a.slots = mvt_detail_conv_rows_slots(Ho, Wo, mvt_detail_conv_rows_tile_rows(ksize, stride, Ho));
   a.in_bf16 = io_flags & MVT_IO_IN_BF16 ? 1 : 0;
   a.out_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
   // background launch (the encoder of later frames on the second stream): an unused dynamic LDS request caps the kernel at one
@@ -567,7 +613,7 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
       else LAUNCH2(TM_, 2, KS_, S_, NW_, false);                                                                                   \
     }                                                                                                                              \
   } while (0)
-  static const int nw8 = getenv("MVT_ROWS_NW8") ? atoi(getenv("MVT_ROWS_NW8")) : 0;  // tuning override
+  const int nw8 = rows_nw8();
   if (ksize == 3 && stride == 1 && nw8 == 1 && Ho % 16 == 0) LAUNCH(2, 3, 1, 8);
   else if (ksize == 3 && stride == 1 && nw8 == 2) LAUNCH(1, 3, 1, 4);
   else if (ksize == 3 && stride == 1) LAUNCH(2, 3, 1, 4);
@@ -588,7 +634,7 @@ __attribute__((visibility("hidden"))) int mvt_detail_stem7x7_rows(const float* i
   RowsArgs a{};
   a.in = in; a.w = w; a.bias = bias; a.out = (float*)out; a.in_stats = nullptr; a.out_part = out_partial;
   a.H = H; a.W = W; a.Cin = 4; a.Cout = Cout; a.ldw = ldw; a.ldo = ldo;
-  a.slots = mvt_detail_conv_rows_slots(Ho, Wo);
+  a.slots = mvt_detail_conv_rows_slots(Ho, Wo, TR);
   a.in_bf16 = 0;
   a.out_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
   const long long tiles = (long long)n * mvt_cdiv(Ho, TR) * mvt_cdiv(Wo, TC);

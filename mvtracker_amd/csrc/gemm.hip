@@ -829,7 +829,8 @@ extern "C" int mvt_gemm_bf16(const float* A, int lda, const unsigned short* Whi,
   return Wlo ? launch_gemm_bf16<true>(a, mvt_stream(stream)) : launch_gemm_bf16<false>(a, mvt_stream(stream));
 }
 
-int mvt_detail_conv_rows_slots(int H, int W);
+int mvt_detail_conv_rows_slots(int Ho, int Wo, int tile_rows);
+int mvt_detail_conv_rows_tile_rows(int ksize, int stride, int Ho);
 int mvt_detail_stem7x7_rows(const float* in, const unsigned short* w, int ldw, const float* bias, void* out, int n, int H, int W, int Cout,
                             int ldo, int io_flags, float* out_partial, hipStream_t stream);
 int mvt_detail_conv_rows(const void* in, const unsigned short* w, int ldw, const float* bias, void* out, int n, int H, int W, int Cin,
@@ -840,9 +841,10 @@ extern "C" int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int 
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
   if (!split && Cin % 32 == 0 && KH == KW && ((KH == 3 && pad == 1) || (KH == 1 && pad == 0)) && stride <= 2)
-    return mvt_detail_conv_rows_slots(Ho, Wo);  // row-tile kernels
+    return mvt_detail_conv_rows_slots(Ho, Wo, mvt_detail_conv_rows_tile_rows(KH, stride, Ho));  // row-tile kernels: one slot per tile
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0) return (int)(mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4);
-  if (!split && Cin == 4 && KH == 7 && KW == 7 && stride == 2 && pad == 3) return mvt_detail_conv_rows_slots(Ho, Wo);  // stem kernel
+  if (!split && Cin == 4 && KH == 7 && KW == 7 && stride == 2 && pad == 3)
+    return mvt_detail_conv_rows_slots(Ho, Wo, mvt_detail_conv_rows_tile_rows(7, 2, Ho));  // stem kernel
   return ((long long)Ho * Wo) % 256 == 0 ? Ho * Wo / 32 : 0;  // im2col tiles are <= 256 rows: they must not straddle images
 }
 
