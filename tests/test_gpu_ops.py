@@ -144,8 +144,9 @@ def test_conv2d_fused_instnorm(hip, cfg, prec):
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     halo = k == 3 and s == 1
     slots = hip.conv2d_stat_slots(H, W, cin, k, k, s, p, prec == "bf16x3")
-    if prec == "bf16":  # row-tile kernels: one slot per 32-pixel row segment
-        assert slots == Ho * ((Wo + 31) // 32)
+    if prec == "bf16":  # row-tile kernels: one slot per workgroup tile (8 rows x 32 pixels; 4 rows for the stride-2 3x3 kernel)
+        tr = 4 if (k == 3 and s == 2) else 8
+        assert slots == ((Ho + tr - 1) // tr) * ((Wo + 31) // 32)
     else:
         assert slots == (((Ho + 7) // 8) * ((Wo + 15) // 16) * 4 if halo else Ho * Wo // 32)
     xin = G(x)
