@@ -186,6 +186,13 @@ int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn* attn, con
                               const unsigned short* w1, const float* b1, const unsigned short* w2, const float* b2, int H,
                               const mvt_block_next* next, int n_next, long long M, int C, float* workspace, void* stream);
 
+/* The updater's input in one launch (cotracker2/blocks.py:456-459 + the first projection): rows < Mp of x [M][ldx] =
+ * tokens [Mp][ldtok] (token_dim <= 592 columns used) . Win^T + bin, rows >= Mp = virtual_tokens[(row - Mp) / S]; x is written,
+ * then y_i = LayerNorm_i(x) . Wn_i^T + bn_i as in mvt_ln_proj_bf16.  win: fragment-major bf16 of [256][592] (zero padded). */
+int mvt_input_proj_bf16(const float* tokens, int ldtok, int token_dim, long long Mp, const unsigned short* win, const float* bin,
+                        const float* virtual_tokens, int S, float* x, int ldx, const mvt_block_next* next, int n_next, long long M, int C,
+                        void* stream);
+
 /* LayerNorm + projections only (x is read, never written): y_i = LayerNorm_i(x) . Wn_i^T + bn_i with the mvt_block_next
  * descriptors of mvt_block_fused_bf16 -- the first q|k|v projection of an updater call. */
 int mvt_ln_proj_bf16(const float* x, int ldx, const mvt_block_next* next, int n_next, long long M, int C, void* stream);
@@ -444,6 +451,7 @@ typedef struct mvt_updater_weights {
   /* optional, for the fused track update of mvt_updateformer_forward (NULL w = not available): the flow head once more as
    * fragment-major bf16 (K of flow2 / flow4 padded to 144) and the feature updater of mvtracker.py:178-179, 393-399 */
   mvt_lin_frag flow0_frag, flow2_frag, flow4_frag, ffeats_updater;
+  mvt_lin_frag input_frag; /* optional: input_transform once more as fragment-major bf16 with K padded to 592 (mvt_input_proj_bf16) */
   const float* ffeats_norm_w; /* GroupNorm(1, 128) affine */
   const float* ffeats_norm_b;
 } mvt_updater_weights;

@@ -69,6 +69,13 @@ struct BlockArgs {
   int ldaq, ldakv, S, nkeys, bmv;
   const float* parts;   // ATT 3: key-split attention partials of mvt_attention_bf16(MVT_ATTN_PARTIALS_ONLY)
   int nsplit;
+  // ATT 4 (MODE 3): x itself is produced here -- rows < Mp: tokens . Win^T + bin; rows >= Mp: the learned virtual token
+  const float* tokx;          // [Mp][ldtok] fp32 token matrix
+  const unsigned short* win;  // fragment-major bf16 of [C][37 * 16]
+  const float* bin;
+  const float* virt;          // [n_virtual][C]
+  int ldtok;
+  long long Mp;
 };
 
 __device__ __forceinline__ bf16x8 ldg_frag(const unsigned short* p) {
@@ -464,7 +471,42 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     for (int e = 0; e < 16; ++e) v[mb][e] = 0.f;
 
   // ---- 1. attention output projection (accumulated into v, x is added afterwards)
-  if (MODE != 2 && ATT == 3) {
+  if (MODE == 3 && ATT == 4) {
+    // Input transform (cotracker2/blocks.py:456-459): the residual stream x is BORN here.  The 581-wide token rows (padded to
+    // 37 k-steps) are staged as bf16 in two halves (19 + 18 k-steps: one half fits the H buffers), x = tokens . Win^T + bin for
+    // the point rows; the rows of the virtual tracks start from their learned tokens.  x is then stored and projected like in
+    // the plain MODE 3 -- one launch instead of GEMM + broadcast + LayerNorm/projection.
+    unsigned short* As = &Hs[0][0];
+    constexpr int LDT = 312, KSA = 19, KSB = 18;
+    static_assert(BM * LDT <= 2 * BM * LDH, "a token half fits the H buffers");
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int k0 = half ? KSA * 16 : 0, kq = (half ? KSB : KSA) * 4;  // float4 per row of this half
+      if (half) __syncthreads();  // every wave is done with the first half
+      for (int f = t; f < BM * kq; f += NT) {
+        const int row = f / kq, c = (f - row * kq) * 4;
+        const long long m = grow(row);
+        u32x2 w = (u32x2){0u, 0u};
+        if (m >= 0 && m < p.Mp && k0 + c < p.ldtok)
+          w = __builtin_bit_cast(u32x2, __builtin_convertvector(*reinterpret_cast<const f32x4*>(p.tokx + m * (long long)p.ldtok + k0 + c), bf16x4));
+        *reinterpret_cast<u32x2*>(&As[row * LDT + c]) = w;
+      }
+      __syncthreads();
+      if (half == 0) gemm_wt<KSA, NMB>(v, p.win + ((long long)wave * (KSA + KSB) * 64 + lane) * 8, &As[r * LDT + 8 * h], LDT, 0);
+      else gemm_wt<KSB, NMB>(v, p.win + (((long long)wave * (KSA + KSB) + KSA) * 64 + lane) * 8, &As[r * LDT + 8 * h], LDT, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const long long m = grow(mb * 32 + r);
+      const bool virt = m >= p.Mp;
+      const long long tk = virt ? (m - p.Mp) / p.S : 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        v[mb][e] = virt ? p.virt[tk * C + c] : v[mb][e] + p.bin[c];
+      }
+    }
+  } else if (MODE != 2 && ATT == 3) {
     // The attention tile from the key-split partials of the virtual<-point attention (one (m, l, O^T) state per split and
     // (frame, head) chunk, in attention_mfma_kernel's accumulator layout).  The tile is frame-major -- the 32 virtual tokens
     // mb = blockIdx.x of frame blockIdx.z -- so wave hd reads the records of its (frame, head) chunk in their NATIVE lane layout
@@ -601,6 +643,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   }
 #pragma unroll
   for (int mb = 0; mb < NMB; ++mb) {
+    if (ATT == 4) break;  // (x was just computed)
     const long long m = grow(mb * 32 + r);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -722,7 +765,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += acc2[mb][4 * g + e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
   }
-  if (MODE == 0 || (p.ws && blockIdx.y == 0)) store_x();  // (never in the projection-only form: x is read-only there)
+  if (MODE == 0 || ATT == 4 || (p.ws && blockIdx.y == 0)) store_x();  // (never in the projection-only form: x is read-only there)
 
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
   bool have = tail_next || early_have;  // the queue already holds this wave's first block of the projection
@@ -932,6 +975,28 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
   } else {
     return MVT_ERR_ARG;
   }
+  return mvt_launch_status();
+}
+
+// Input transform + virtual tokens + first projections in one launch (ATT 4 of MODE 3).
+extern "C" int mvt_input_proj_bf16(const float* tokens, int ldtok, int token_dim, long long Mp, const unsigned short* win, const float* bin,
+                                   const float* virtual_tokens, int S, float* x, int ldx, const mvt_block_next* next, int n_next, long long M,
+                                   int Cc, void* stream) {
+  MVT_REQUIRE(tokens && win && bin && virtual_tokens && x && next && n_next >= 1 && n_next <= MVT_BLOCK_MAX_NEXT && Cc == C);
+  MVT_REQUIRE(M > 0 && Mp >= 0 && Mp <= M && S >= 1 && (M - Mp) % S == 0 && token_dim >= 1 && token_dim <= 37 * 16 && ldtok >= token_dim);
+  MVT_REQUIRE(ldtok % 4 == 0 && ldx % 4 == 0 && ldx >= C && ((uintptr_t)tokens % 16 == 0) && ((uintptr_t)win % 16 == 0) && ((uintptr_t)x % 16 == 0));
+  BlockArgs a{};
+  a.x = x; a.ldx = ldx; a.M = M; a.n_next = n_next; a.H = 4 * C; a.ws = nullptr; a.S = S;
+  a.tokx = tokens; a.ldtok = ldtok; a.win = win; a.bin = bin; a.virt = virtual_tokens; a.Mp = Mp;
+  for (int q = 0; q < n_next; ++q) {
+    const mvt_block_next& nx = next[q];
+    MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
+    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo) && (nx.y_bf16 == 0 || nx.y_bf16 == 1));
+    a.next[q] = nx;
+    if (nx.row_hi == 0) a.next[q].row_hi = M;
+  }
+  hipLaunchKernelGGL((block_fused_bf16<2, 3, 4>), dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
   return mvt_launch_status();
 }
 

@@ -115,13 +115,19 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
 
   // ticket counters of the fused attention merge: zero on entry of the first use, left zero by every launch
   if (hipMemsetAsync(attn_ws + 4LL * S * HEADS * 64 * 68, 0, (size_t)S * HEADS * 4, mvt_stream(stream)) != hipSuccess) return MVT_ERR_HIP_BASE;
-  // tokens: input transform of the point rows, learned virtual tokens repeated over the S frames (blocks.py:456-459)
-  MVT_TRY(mvt_gemm_bf16(x, ldx, w->input_transform.w, nullptr, w->input_transform.ldw, w->input_transform.b, nullptr, 0, tok, H_, (int)Mp, H_,
-                        w->token_dim, MVT_ACT_NONE, 0, stream));
-  MVT_TRY(mvt_broadcast_rows(w->virtual_tokens, vt, H_, NV, S, H_, stream));
+  // tokens: input transform of the point rows, learned virtual tokens repeated over the S frames (blocks.py:456-459), and the
+  // first time-attention q|k|v projection -- one launch when the fragment-major input weights are available
   {
     const mvt_block_next nx = next_of(w->time_blk[0].qkv, qkv, ld3, 0, 0);
-    MVT_TRY(mvt_ln_proj_bf16(tok, H_, &nx, 1, M, H_, stream));
+    if (w->input_frag.w && w->token_dim <= 592 && w->input_frag.K == 592) {
+      MVT_TRY(mvt_input_proj_bf16(x, ldx, w->token_dim, Mp, w->input_frag.w, w->input_frag.b, w->virtual_tokens, S, tok, H_, &nx, 1, M, H_,
+                                  stream));
+    } else {
+      MVT_TRY(mvt_gemm_bf16(x, ldx, w->input_transform.w, nullptr, w->input_transform.ldw, w->input_transform.b, nullptr, 0, tok, H_, (int)Mp,
+                            H_, w->token_dim, MVT_ACT_NONE, 0, stream));
+      MVT_TRY(mvt_broadcast_rows(w->virtual_tokens, vt, H_, NV, S, H_, stream));
+      MVT_TRY(mvt_ln_proj_bf16(tok, H_, &nx, 1, M, H_, stream));
+    }
   }
   for (int i = 0; i < w->depth; ++i) {
     const bool last = i + 1 == w->depth;

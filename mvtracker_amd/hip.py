@@ -58,6 +58,7 @@ SIGNATURES = {
     "mvt_knn_scan": [P, LL, P, I, I, I, I, I, I, I, P, P, I, I, I, I, I, P, I, I, P],
     "mvt_knn_merge": [P, I, I, I, I, LL, P, P],
     "mvt_ln_proj_bf16": [P, I, P, I, LL, I, P],
+    "mvt_input_proj_bf16": [P, I, I, LL, P, P, P, I, P, I, P, I, LL, I, P],
     "mvt_adapter_best_view": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mvt_knn_scan_levels": [I, P, P, I, I, I, I, I, I, I, P],
     "mvt_knn_merge_levels": [I, P, I, I, I, P],
@@ -271,6 +272,16 @@ def ln_proj_bf16(x, ldx, nexts, M, Cc):
         arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],
                            nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)), 1 if nx["y"].dtype == torch.bfloat16 else 0)
     _call("mvt_ln_proj_bf16", _ptr(x), ldx, C.cast(arr, C.c_void_p), len(nexts), M, Cc, _stream())
+
+
+def input_proj_bf16(tokens, ldtok, token_dim, Mp, win, bin_, virtual_tokens, S, x, ldx, nexts, M, Cc):
+    """x = [tokens . Win^T + b ; virtual tokens] written, then the LayerNorm + projections of ``nexts`` (one launch)."""
+    arr = (BlockNext * len(nexts))()
+    for i, nx in enumerate(nexts):
+        arr[i] = BlockNext(_ptr(nx["w"]), _ptr(nx["b"]), _ptr(nx.get("lnw")), _ptr(nx.get("lnb")), _ptr(nx["y"]), nx["ldw"], nx["N"],
+                           nx["ldy"], nx["eps"], *nx.get("rows", (0, 0)), 1 if nx["y"].dtype == torch.bfloat16 else 0)
+    _call("mvt_input_proj_bf16", _ptr(_f32c(tokens)), ldtok, token_dim, Mp, _ptr(win), _ptr(bin_), _ptr(virtual_tokens), S, _ptr(x), ldx,
+          C.cast(arr, C.c_void_p), len(nexts), M, Cc, _stream())
 
 
 def mlp_fused_bf16(x, ldx, w1, ldw1, b1, w2, ldw2, b2, M, Cc, H, eps):
@@ -489,6 +500,7 @@ class UpdaterWeights(C.Structure):
                 ("time_blk", UpdaterBlock * UPDATER_MAX_DEPTH), ("v2p", UpdaterBlock * UPDATER_MAX_DEPTH),
                 ("vself", UpdaterBlock * UPDATER_MAX_DEPTH), ("p2v", UpdaterBlock * UPDATER_MAX_DEPTH),
                 ("flow0_frag", LinFrag), ("flow2_frag", LinFrag), ("flow4_frag", LinFrag), ("ffeats_updater", LinFrag),
+                ("input_frag", LinFrag),
                 ("ffeats_norm_w", C.c_void_p), ("ffeats_norm_b", C.c_void_p)]
 
 

@@ -132,6 +132,7 @@ class MVTracker(nn.Module):
         # launch (all variants are bit-identical to the separate launches)
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
+        self.fuse_input = os.environ.get("MVT_FUSE_INPUT", "1") != "0"  # input transform + virtual tokens + first q|k|v in one launch
         self.fuse_head = os.environ.get("MVT_FUSE_HEAD", "1") != "0"  # flow head + track / feature update in one kernel
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
         self.fuse_ln = False
@@ -221,7 +222,7 @@ class MVTracker(nn.Module):
     # ------------------------------------------------------------------ weight packing for the kernels
     def _signature(self, dev):
         assert self.precision in ("fp32", "bf16x3", "bf16"), self.precision
-        return (str(dev), self.precision, self.fuse_attention) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        return (str(dev), self.precision, self.fuse_attention, self.fuse_input) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
     def _pack(self, dev) -> dict:
         sig = self._signature(dev)
@@ -340,6 +341,8 @@ class MVTracker(nn.Module):
 
         w.flow0_frag, w.flow2_frag, w.flow4_frag = frag_of(u + "flow_head.0", h), frag_of(u + "flow_head.2", 144), frag_of(u + "flow_head.4", 144)
         w.ffeats_updater = frag_of("ffeats_updater.0", self.latent_dim)
+        if self.fuse_input and self.updateformer_input_dim <= 592:
+            w.input_frag = frag_of(u + "input_transform", 592)
         gw, gb = sd["ffeats_norm.weight"].contiguous(), sd["ffeats_norm.bias"].contiguous()
         keep.extend([gw, gb])
         w.ffeats_norm_w, w.ffeats_norm_b = gw.data_ptr(), gb.data_ptr()
