@@ -462,6 +462,26 @@ long long mvt_updateformer_workspace_bytes(int n, int S); /* host; -1 on bad arg
 int mvt_updateformer_forward(const mvt_updater_weights* w /* host struct of device pointers */, const float* x, int ldx, int n,
                              float* delta, int ldd, float* coords, float* ffeats, int* nan_flag, void* workspace,
                              long long workspace_bytes, void* stream);
+/* mvt_updateformer_forward with the 581-wide token rows ASSEMBLED inside its first kernel (mvt_token_input_proj_bf16: the
+ * arithmetic of mvt_token_assemble) instead of read from a token matrix: one refinement iteration after the correlation is then
+ * this single call.  coords [n][S][3], fcorr [n][S][Fc], ffeats [n][S][Cf], mask_vis [n][S][2], pos [n][D], time_embed [S][D],
+ * D = 3E + 3 + Fc + Cf + 2 = token_dim.  Needs w->input_frag. */
+typedef struct mvt_token_inputs {
+  const float* coords;
+  const float* fcorr;
+  const float* ffeats;
+  const float* mask_vis;
+  const float* pos;
+  const float* time_embed;
+  int Fc, Cf, E;
+} mvt_token_inputs;
+int mvt_updateformer_forward_tokens(const mvt_updater_weights* w, const mvt_token_inputs* tokens, int n, float* delta, int ldd,
+                                    float* coords, float* ffeats, int* nan_flag, void* workspace, long long workspace_bytes, void* stream);
+int mvt_token_input_proj_bf16(const float* coords, const float* fcorr, int Fc, const float* ffeats, int Cf, const float* mask_vis,
+                              const float* pos, const float* time_embed, int n_tracks, int S, int E, const unsigned short* win,
+                              const float* bin, const float* virtual_tokens, float* x, int ldx, const mvt_block_next* next, int n_next,
+                              long long M, int C, void* stream);
+
 /* The head alone: flow head (256 -> 131 -> 131 -> 131, ReLU) on tok [rows][ldt] + track / feature update, see above.  w0 / w2 /
  * w4 / wu fragment-major bf16 of [131][256], [131][144], [131][144], [128][128] (mvt_pack_frag_bf16, zero padded). */
 int mvt_update_head_bf16(const float* tok, int ldt, const unsigned short* w0, const float* b0, const unsigned short* w2,

@@ -76,7 +76,37 @@ struct BlockArgs {
   const float* virt;          // [n_virtual][C]
   int ldtok;
   long long Mp;
+  // ... or the token rows are ASSEMBLED here (tokx == null; mvtracker.py:374-387, the arithmetic of token_assemble_kernel):
+  const float* t_coords;    // [n][S][3]
+  const float* t_fcorr;     // [n][S][Fc]
+  const float* t_ffeats;    // [n][S][Cf]
+  const float* t_maskvis;   // [n][S][2]
+  const float* t_pos;       // [n][D]
+  const float* t_time;      // [S][D]
+  int t_E, t_Fc, t_Cf, t_D;
 };
+
+// one element of the updater's input token (mvtracker.py:379-387): [sin|cos flow embedding 3E | flow 3 | fcorr Fc | ffeats Cf |
+// track mask, visibility 2] + positional + time embedding -- the same expressions, in the same order, as token_assemble_kernel
+__device__ __forceinline__ float token_elem(const BlockArgs& p, long long row, int n, int sidx, int d, const float (&fl)[3]) {
+  const int E = p.t_E, Fc = p.t_Fc, Cf = p.t_Cf;
+  float v;
+  if (d < 3 * E) {
+    const int a = d / E, w = d - a * E;
+    const float div = (float)(w & ~1) * (1000.0f / (float)E);
+    const float arg = fl[a] * div;
+    v = (w & 1) ? cosf(arg) : sinf(arg);
+  } else if (d < 3 * E + 3) {
+    v = fl[d - 3 * E];
+  } else if (d < 3 * E + 3 + Fc) {
+    v = p.t_fcorr[row * Fc + (d - 3 * E - 3)];
+  } else if (d < 3 * E + 3 + Fc + Cf) {
+    v = p.t_ffeats[row * Cf + (d - 3 * E - 3 - Fc)];
+  } else {
+    v = p.t_maskvis[row * 2 + (d - 3 * E - 3 - Fc - Cf)];
+  }
+  return (v + p.t_pos[(long long)n * p.t_D + d]) + p.t_time[(long long)sidx * p.t_D + d];
+}
 
 __device__ __forceinline__ bf16x8 ldg_frag(const unsigned short* p) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
@@ -487,8 +517,19 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         const int row = f / kq, c = (f - row * kq) * 4;
         const long long m = grow(row);
         u32x2 w = (u32x2){0u, 0u};
-        if (m >= 0 && m < p.Mp && k0 + c < p.ldtok)
-          w = __builtin_bit_cast(u32x2, __builtin_convertvector(*reinterpret_cast<const f32x4*>(p.tokx + m * (long long)p.ldtok + k0 + c), bf16x4));
+        if (p.tokx) {
+          if (m >= 0 && m < p.Mp && k0 + c < p.ldtok)
+            w = __builtin_bit_cast(u32x2, __builtin_convertvector(*reinterpret_cast<const f32x4*>(p.tokx + m * (long long)p.ldtok + k0 + c), bf16x4));
+        } else if (m >= 0 && m < p.Mp && k0 + c < p.t_D) {  // assemble the token elements (no token matrix in HBM at all)
+          const int n = (int)(m / p.S), sidx = (int)(m - (long long)n * p.S);
+          const float* cc = p.t_coords + m * 3;
+          const float* c0 = p.t_coords + (long long)n * p.S * 3;
+          const float fl[3] = {cc[0] - c0[0], cc[1] - c0[1], cc[2] - c0[2]};
+          f32x4 tv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tv[e] = k0 + c + e < p.t_D ? token_elem(p, m, n, sidx, k0 + c + e, fl) : 0.f;
+          w = __builtin_bit_cast(u32x2, __builtin_convertvector(tv, bf16x4));
+        }
         *reinterpret_cast<u32x2*>(&As[row * LDT + c]) = w;
       }
       __syncthreads();
@@ -988,6 +1029,34 @@ extern "C" int mvt_input_proj_bf16(const float* tokens, int ldtok, int token_dim
   BlockArgs a{};
   a.x = x; a.ldx = ldx; a.M = M; a.n_next = n_next; a.H = 4 * C; a.ws = nullptr; a.S = S;
   a.tokx = tokens; a.ldtok = ldtok; a.win = win; a.bin = bin; a.virt = virtual_tokens; a.Mp = Mp;
+  for (int q = 0; q < n_next; ++q) {
+    const mvt_block_next& nx = next[q];
+    MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
+    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo) && (nx.y_bf16 == 0 || nx.y_bf16 == 1));
+    a.next[q] = nx;
+    if (nx.row_hi == 0) a.next[q].row_hi = M;
+  }
+  hipLaunchKernelGGL((block_fused_bf16<2, 3, 4>), dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
+  return mvt_launch_status();
+}
+
+// ... the same with the token rows assembled in the kernel (no token matrix): mvt_token_assemble + mvt_input_proj_bf16 in one launch.
+extern "C" int mvt_token_input_proj_bf16(const float* coords, const float* fcorr, int Fc, const float* ffeats, int Cf, const float* mask_vis,
+                                         const float* pos, const float* time_embed, int n_tracks, int S, int E,
+                                         const unsigned short* win, const float* bin, const float* virtual_tokens, float* x, int ldx,
+                                         const mvt_block_next* next, int n_next, long long M, int Cc, void* stream) {
+  MVT_REQUIRE(coords && fcorr && ffeats && mask_vis && pos && time_embed && win && bin && virtual_tokens && x && next);
+  MVT_REQUIRE(n_next >= 1 && n_next <= MVT_BLOCK_MAX_NEXT && Cc == C && n_tracks > 0 && S >= 1 && E > 0 && E % 2 == 0 && Fc > 0 && Cf > 0);
+  const int D = 3 * E + 3 + Fc + Cf + 2;
+  const long long Mp = (long long)n_tracks * S;
+  MVT_REQUIRE(D <= 37 * 16 && M >= Mp && (M - Mp) % S == 0 && ldx % 4 == 0 && ldx >= C);
+  MVT_REQUIRE(((uintptr_t)win % 16 == 0) && ((uintptr_t)x % 16 == 0));
+  BlockArgs a{};
+  a.x = x; a.ldx = ldx; a.M = M; a.n_next = n_next; a.H = 4 * C; a.ws = nullptr; a.S = S;
+  a.tokx = nullptr; a.win = win; a.bin = bin; a.virt = virtual_tokens; a.Mp = Mp;
+  a.t_coords = coords; a.t_fcorr = fcorr; a.t_ffeats = ffeats; a.t_maskvis = mask_vis; a.t_pos = pos; a.t_time = time_embed;
+  a.t_E = E; a.t_Fc = Fc; a.t_Cf = Cf; a.t_D = D;
   for (int q = 0; q < n_next; ++q) {
     const mvt_block_next& nx = next[q];
     MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);

@@ -62,10 +62,14 @@ extern "C" long long mvt_updateformer_workspace_bytes(int n, int S) {
     if (rc_ != MVT_OK) return rc_; \
   } while (0)
 
-extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const float* x, int ldx, int n, float* delta, int ldd,
-                                        float* coords, float* ffeats, int* nan_flag, void* workspace, long long workspace_bytes,
-                                        void* stream) {
-  MVT_REQUIRE(w && x && workspace && n > 0 && (delta || coords));
+static int updater_run(const mvt_updater_weights* w, const float* x, int ldx, const mvt_token_inputs* ti, int n, float* delta, int ldd,
+                       float* coords, float* ffeats, int* nan_flag, void* workspace, long long workspace_bytes, void* stream) {
+  MVT_REQUIRE(w && (x || ti) && workspace && n > 0 && (delta || coords));
+  if (!x) {
+    MVT_REQUIRE(ti->coords && ti->fcorr && ti->ffeats && ti->mask_vis && ti->pos && ti->time_embed && w->input_frag.w);
+    MVT_REQUIRE(3 * ti->E + 3 + ti->Fc + ti->Cf + 2 == w->token_dim);
+    ldx = (w->token_dim + 3) / 4 * 4;
+  }
   MVT_REQUIRE(!coords || (ffeats && w->flow0_frag.w && w->flow2_frag.w && w->flow4_frag.w && w->ffeats_updater.w && w->ffeats_norm_w &&
                           w->ffeats_norm_b));
   MVT_REQUIRE(w->hidden == H_ && w->heads == HEADS && w->dim_head == DH_ && w->n_virtual == NV && w->out_dim == OUT);
@@ -119,7 +123,11 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
   // first time-attention q|k|v projection -- one launch when the fragment-major input weights are available
   {
     const mvt_block_next nx = next_of(w->time_blk[0].qkv, qkv, ld3, 0, 0);
-    if (w->input_frag.w && w->token_dim <= 592 && w->input_frag.K == 592) {
+    if (!x) {  // token rows assembled inside the kernel: no token matrix at all
+      MVT_REQUIRE(w->token_dim <= 592 && w->input_frag.K == 592);
+      MVT_TRY(mvt_token_input_proj_bf16(ti->coords, ti->fcorr, ti->Fc, ti->ffeats, ti->Cf, ti->mask_vis, ti->pos, ti->time_embed, n, S, ti->E,
+                                        w->input_frag.w, w->input_frag.b, w->virtual_tokens, tok, H_, &nx, 1, M, H_, stream));
+    } else if (w->input_frag.w && w->token_dim <= 592 && w->input_frag.K == 592) {
       MVT_TRY(mvt_input_proj_bf16(x, ldx, w->token_dim, Mp, w->input_frag.w, w->input_frag.b, w->virtual_tokens, S, tok, H_, &nx, 1, M, H_,
                                   stream));
     } else {
@@ -199,4 +207,18 @@ extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const floa
   MVT_TRY(mvt_gemm_bf16(h1, L.ldh, w->flow2.w, nullptr, w->flow2.ldw, w->flow2.b, nullptr, 0, h2, L.ldh, (int)Mp, L.ldh, OUT, MVT_ACT_RELU, 0, stream));
   MVT_TRY(mvt_gemm_bf16(h2, L.ldh, w->flow4.w, nullptr, w->flow4.ldw, w->flow4.b, nullptr, 0, delta, ldd, (int)Mp, OUT, OUT, MVT_ACT_NONE, 0, stream));
   return MVT_OK;
+}
+
+extern "C" int mvt_updateformer_forward(const mvt_updater_weights* w, const float* x, int ldx, int n, float* delta, int ldd,
+                                        float* coords, float* ffeats, int* nan_flag, void* workspace, long long workspace_bytes,
+                                        void* stream) {
+  MVT_REQUIRE(x);
+  return updater_run(w, x, ldx, nullptr, n, delta, ldd, coords, ffeats, nan_flag, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvt_updateformer_forward_tokens(const mvt_updater_weights* w, const mvt_token_inputs* tokens, int n, float* delta, int ldd,
+                                               float* coords, float* ffeats, int* nan_flag, void* workspace, long long workspace_bytes,
+                                               void* stream) {
+  MVT_REQUIRE(tokens);
+  return updater_run(w, nullptr, 0, tokens, n, delta, ldd, coords, ffeats, nan_flag, workspace, workspace_bytes, stream);
 }

@@ -79,6 +79,8 @@ SIGNATURES = {
     "mvt_track_metrics": [P, P, P, P, P, I, I, I, P, I, F, P, I, P],
     "mvt_updateformer_workspace_bytes": [I, I],
     "mvt_updateformer_forward": [P, P, I, I, P, I, P, P, P, P, LL, P],
+    "mvt_updateformer_forward_tokens": [P, P, I, P, I, P, P, P, P, LL, P],
+    "mvt_token_input_proj_bf16": [P, P, I, P, I, P, P, P, I, I, I, P, P, P, P, I, P, I, LL, I, P],
     "mvt_update_head_bf16": [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, LL, I, I, P, P],
 }
 _RET = {"mvt_build_arch": C.c_char_p, "mvt_stream_create_cu_mask": C.c_void_p, "mvt_updateformer_workspace_bytes": C.c_longlong}
@@ -556,3 +558,18 @@ def track_metrics(gt_tracks, pred_tracks, gt_visible, pred_occluded, query_frame
     th = (C.c_float * K)(*[float(t) for t in thresholds])
     _call("mvt_track_metrics", _ptr(_f32c(gt_tracks)), _ptr(_f32c(pred_tracks)), _ptr(gt_visible), _ptr(pred_occluded), _ptr(query_frame),
           T, N, D, C.cast(th, C.c_void_p), K, float(survival_threshold), _ptr(out), out.shape[1], _stream())
+
+
+class TokenInputs(C.Structure):
+    """mvt_token_inputs."""
+    _fields_ = [("coords", C.c_void_p), ("fcorr", C.c_void_p), ("ffeats", C.c_void_p), ("mask_vis", C.c_void_p), ("pos", C.c_void_p),
+                ("time_embed", C.c_void_p), ("Fc", C.c_int), ("Cf", C.c_int), ("E", C.c_int)]
+
+
+def updateformer_forward_tokens(weights: UpdaterWeights, coords, fcorr, Fc, ffeats, Cf, mask_vis, pos, time_embed, E, n, delta, ldd, workspace,
+                                upd_coords=None, upd_ffeats=None, nan_flag=None):
+    """``updateformer_forward`` with the token rows assembled inside its first kernel (no token matrix)."""
+    ti = TokenInputs(_ptr(_f32c(coords)), _ptr(_f32c(fcorr)), _ptr(_f32c(ffeats)), _ptr(_f32c(mask_vis)), _ptr(_f32c(pos)), _ptr(_f32c(time_embed)),
+                     Fc, Cf, E)
+    _call("mvt_updateformer_forward_tokens", C.addressof(weights), C.addressof(ti), n, _ptr(delta), ldd, _ptr(upd_coords), _ptr(upd_ffeats),
+          _ptr(nan_flag), _ptr(workspace), workspace.numel(), _stream())

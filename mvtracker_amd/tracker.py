@@ -132,6 +132,7 @@ class MVTracker(nn.Module):
         # launch (all variants are bit-identical to the separate launches)
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
+        self.fuse_tokens = os.environ.get("MVT_FUSE_TOKENS", "1") != "0"  # ... with the token rows assembled inside that launch
         self.fuse_input = os.environ.get("MVT_FUSE_INPUT", "1") != "0"  # input transform + virtual tokens + first q|k|v in one launch
         self.fuse_head = os.environ.get("MVT_FUSE_HEAD", "1") != "0"  # flow head + track / feature update in one kernel
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
@@ -834,6 +835,14 @@ class MVTracker(nn.Module):
                         hip.knn_merge(kl, m, S, K, nsegs[lvl], P, idx[lvl][n0:])
             hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0, 1,
                                 T, K, fcorr, Fc, 0)
+            if (trace is None and "updater_struct" in pk and self.fuse_head and self.fuse_input and self.fuse_tokens
+                    and pk["updater_struct"].input_frag.w):
+                # everything after the correlation in ONE library call: token rows assembled inside the updater's first kernel,
+                # the transformer, flow head and track / feature update (no token matrix, no delta tensor in HBM)
+                ws = self._workspace(hip.updateformer_workspace_bytes(n, S), dev)
+                hip.updateformer_forward_tokens(pk["updater_struct"], coords, fcorr, Fc, ffeats, C, mask_vis, pos, pk["time_embed"], E, n, None, ldd,
+                                                ws, coords, ffeats, nan_flag)
+                continue
             hip.token_assemble(coords, fcorr, Fc, ffeats, C, mask_vis, pos, pk["time_embed"], n, S, E, x, ldx)
             # (the delta tensor itself only leaves the fused head for tracing)
             updated = self._update_former(pk, x, ldx, n, delta if trace is not None else None, ldd, coords, ffeats, nan_flag) \

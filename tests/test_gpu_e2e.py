@@ -632,3 +632,24 @@ def test_updater_fused_input_close_to_unfused(model, n):
     rel = ((a - b).abs().max() / b.abs().max()).item()
     assert rel < 2e-2, rel
     assert ((a - b).abs().mean() / b.abs().mean()).item() < 2e-3
+
+
+def test_in_kernel_token_assembly_bit_identical(model):
+    """One library call per refinement iteration (token rows assembled inside the updater's first kernel,
+    mvt_updateformer_forward_tokens) against token_assemble + mvt_updateformer_forward: the same token arithmetic, the same GEMM
+    order -> identical tracks and visibilities, bit for bit (two windows, late queries)."""
+    clip = synth.make_clip(32, V=2, T=18, H=128, W=128, N=40, late_queries=True, query_frames=(3, 7))
+    a = args_of(clip, DEV)
+    with _with_precision(model, "bf16"):
+        old = model.fuse_tokens
+        try:
+            model.fuse_tokens = True
+            r1 = model(*a, iters=4)
+            t1, v1 = r1["traj_e"].clone(), r1["vis_e"].clone()
+            model.fuse_tokens = False
+            r2 = model(*a, iters=4)
+            torch.cuda.synchronize()
+        finally:
+            model.fuse_tokens = old
+    model.check_finite()
+    assert torch.equal(t1, r2["traj_e"]) and torch.equal(v1, r2["vis_e"])
