@@ -181,6 +181,8 @@ def main():
         return f
 
     hip.corr_gather_dot = timed(real_corr, corr_ev, lambda *c, **k: c[7] * c[8])          # rows = N * S
+    # (bf16 mode runs everything after the correlation -- token assembly, updater, flow head, track update -- as ONE library call)
+    hip.updateformer_forward_tokens = timed(hip.updateformer_forward_tokens, upd_ev, lambda w, co, fc, Fc, ff, Cf, mv, po, te, E, n, *r, **k: n)
     model._update_former = timed(real_upd, upd_ev, lambda pk, x, ldx, n, *r, **k: n)       # tracks of the call
     model._encode = timed(real_enc, enc_ev, lambda pk, x4, n, *r, **k: n)                  # images of the chunk
 
