@@ -270,7 +270,14 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
   const int Ho = (p.H + 2 * G::PAD - KS) / S + 1, Wo = (p.W + 2 * G::PAD - KS) / S + 1;
   const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + G::ROWS - 1) / G::ROWS;
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  int b = blockIdx.x;
+  // XCD-aware tile order (cdna_hip_programming.md T1): consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
+  // L2.  Tiles that share input -- the Cout tiles of one pixel tile read the same patch, neighbouring pixel tiles share their halo
+  // rows / columns -- are consecutive in TILE order, so each XCD is given a contiguous run of tiles (bijective for any grid size).
+  int b;
+  {
+    const unsigned nwg = gridDim.x, q = nwg / 8, rr = nwg % 8, xcd = blockIdx.x % 8;
+    b = (int)((xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + blockIdx.x / 8);
+  }
   const int tn = b % tiles_n; b /= tiles_n;
   const int tx = b % tiles_x; b /= tiles_x;
   const int ty = b % tiles_y;
