@@ -462,6 +462,25 @@ long long mvt_updateformer_workspace_bytes(int n, int S); /* host; -1 on bad arg
 int mvt_updateformer_forward(const mvt_updater_weights* w /* host struct of device pointers */, const float* x, int ldx, int n,
                              float* delta, int ldd, float* coords, float* ffeats, int* nan_flag, void* workspace,
                              long long workspace_bytes, void* stream);
+/* mvt_encoder_forward = BasicEncoder.forward (spatracker/blocks.py:214-284) on n images as one call: x4 [n][H][W][4] normalised
+ * RGB (mvt_rgb_*_to_nhwc4) -> out_rows [n][H/4][W/4][ldo] (latent_dim columns; bf16 when out_bf16 -- the frame store of bf16 mode).
+ * bf16 mode with bf16 activations.  conv[i]: row-major bf16 weights [Cout][ldw] with rows (kh, kw, cin) as mvt_conv2d_bf16 takes them
+ * (the 7x7 stem as [64][7][8][4]) + fp32 bias, in the order: 0 conv1; for layer l = 1..4: 1 + 5(l-1) + {0 .0.conv1, 1 .0.conv2,
+ * 2 .0.downsample.0 (unused for l = 1), 3 .1.conv1, 4 .1.conv2}; 21 conv2; 22 conv3.  workspace: mvt_encoder_workspace_bytes bytes,
+ * 256-B aligned, no state between calls.  background: launch the convolutions at reduced occupancy (MVT_IO_BACKGROUND). */
+#define MVT_ENCODER_CONVS 23
+typedef struct mvt_conv_weights {
+  const unsigned short* w;
+  const float* b;
+} mvt_conv_weights;
+typedef struct mvt_encoder_weights {
+  int latent_dim;
+  mvt_conv_weights conv[MVT_ENCODER_CONVS];
+} mvt_encoder_weights;
+long long mvt_encoder_workspace_bytes(int n, int H, int W, int latent_dim); /* host; -1 on bad arguments */
+int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4, int n, int H, int W, void* out_rows, int ldo, int out_bf16,
+                        void* workspace, long long workspace_bytes, int background, void* stream);
+
 /* mvt_updateformer_forward with the 581-wide token rows ASSEMBLED inside its first kernel (mvt_token_input_proj_bf16: the
  * arithmetic of mvt_token_assemble) instead of read from a token matrix: one refinement iteration after the correlation is then
  * this single call.  coords [n][S][3], fcorr [n][S][Fc], ffeats [n][S][Cf], mask_vis [n][S][2], pos [n][D], time_embed [S][D],

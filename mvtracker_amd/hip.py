@@ -77,13 +77,15 @@ SIGNATURES = {
     "mvt_window_prepare": [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P],
     "mvt_window_store": [P, P, P, I, I, I, I, I, P, P, P, P],
     "mvt_track_metrics": [P, P, P, P, P, I, I, I, P, I, F, P, I, P],
+    "mvt_encoder_workspace_bytes": [I, I, I, I],
+    "mvt_encoder_forward": [P, P, I, I, I, P, I, I, P, LL, I, P],
     "mvt_updateformer_workspace_bytes": [I, I],
     "mvt_updateformer_forward": [P, P, I, I, P, I, P, P, P, P, LL, P],
     "mvt_updateformer_forward_tokens": [P, P, I, P, I, P, P, P, P, LL, P],
     "mvt_token_input_proj_bf16": [P, P, I, P, I, P, P, P, I, I, I, P, P, P, P, I, P, I, LL, I, P],
     "mvt_update_head_bf16": [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, LL, I, I, P, P],
 }
-_RET = {"mvt_build_arch": C.c_char_p, "mvt_stream_create_cu_mask": C.c_void_p, "mvt_updateformer_workspace_bytes": C.c_longlong}
+_RET = {"mvt_build_arch": C.c_char_p, "mvt_stream_create_cu_mask": C.c_void_p, "mvt_encoder_workspace_bytes": C.c_longlong, "mvt_updateformer_workspace_bytes": C.c_longlong}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = header / library mismatch
@@ -573,3 +575,26 @@ def updateformer_forward_tokens(weights: UpdaterWeights, coords, fcorr, Fc, ffea
                      Fc, Cf, E)
     _call("mvt_updateformer_forward_tokens", C.addressof(weights), C.addressof(ti), n, _ptr(delta), ldd, _ptr(upd_coords), _ptr(upd_ffeats),
           _ptr(nan_flag), _ptr(workspace), workspace.numel(), _stream())
+
+
+ENCODER_CONVS = 23
+
+
+class ConvWeights(C.Structure):
+    """mvt_conv_weights."""
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+
+
+class EncoderWeights(C.Structure):
+    """mvt_encoder_weights (host struct of device pointers; keep the tensors referenced)."""
+    _fields_ = [("latent_dim", C.c_int), ("conv", ConvWeights * ENCODER_CONVS)]
+
+
+def encoder_workspace_bytes(n, H, W, Cc) -> int:
+    return int(_lib.mvt_encoder_workspace_bytes(n, H, W, Cc))
+
+
+def encoder_forward(weights: EncoderWeights, x4, n, H, W, out_rows, ldo, workspace, background=False):
+    """BasicEncoder.forward as one library call (bf16 mode): x4 (n,H,W,4) fp32 -> out_rows (n,H/4,W/4,ldo) fp32 or bf16."""
+    _call("mvt_encoder_forward", C.addressof(weights), _ptr(_f32c(x4)), n, H, W, _ptr(out_rows), ldo,
+          1 if out_rows.dtype == torch.bfloat16 else 0, _ptr(workspace), workspace.numel(), 1 if background else 0, _stream())

@@ -132,6 +132,7 @@ class MVTracker(nn.Module):
         # launch (all variants are bit-identical to the separate launches)
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
+        self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
         self.fuse_tokens = os.environ.get("MVT_FUSE_TOKENS", "1") != "0"  # ... with the token rows assembled inside that launch
         self.fuse_input = os.environ.get("MVT_FUSE_INPUT", "1") != "0"  # input transform + virtual tokens + first q|k|v in one launch
         self.fuse_head = os.environ.get("MVT_FUSE_HEAD", "1") != "0"  # flow head + track / feature update in one kernel
@@ -223,7 +224,7 @@ class MVTracker(nn.Module):
     # ------------------------------------------------------------------ weight packing for the kernels
     def _signature(self, dev):
         assert self.precision in ("fp32", "bf16x3", "bf16"), self.precision
-        return (str(dev), self.precision, self.fuse_attention, self.fuse_input) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        return (str(dev), self.precision, self.fuse_attention, self.fuse_input, self.composite_encoder) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
     def _pack(self, dev) -> dict:
         sig = self._signature(dev)
@@ -288,6 +289,17 @@ class MVTracker(nn.Module):
         pk["virtual"] = sd[u + "virual_tracks"].reshape(self.nv, self.hidden).contiguous()
         if self._composite_updater_ok():
             pk["updater_struct"] = self._updater_struct(pk, sd, matrix)
+        if self._composite_encoder_ok():
+            ew = hip.EncoderWeights()
+            ew.latent_dim = self.latent_dim
+            names = ["fnet.conv1"]
+            for li in range(1, 5):
+                names += [f"fnet.layer{li}.0.conv1", f"fnet.layer{li}.0.conv2", f"fnet.layer{li}.0.downsample.0" if li > 1 else f"fnet.layer{li}.0.conv1",
+                          f"fnet.layer{li}.1.conv1", f"fnet.layer{li}.1.conv2"]
+            names += ["fnet.conv2", "fnet.conv3"]
+            for i, nm in enumerate(names):  # (layer 1 has no downsample conv: slot 3 repeats a valid pointer and is never used)
+                ew.conv[i].w, ew.conv[i].b = pk[nm][0][0].data_ptr(), pk[nm][1].data_ptr()
+            pk["encoder_struct"] = ew
         pk["ffeats_norm"] = (sd["ffeats_norm.weight"].contiguous(), sd["ffeats_norm.bias"].contiguous())
         lin("ffeats_updater.0")
         pk["vis"] = (sd["vis_predictor.0.weight"].reshape(-1).contiguous(), sd["vis_predictor.0.bias"].contiguous())
@@ -304,6 +316,11 @@ class MVTracker(nn.Module):
         return (self.precision == "bf16" and self.hidden == 256 and self.num_heads == 6 and self.dim_head == 48 and self.nv == 64
                 and self.latent_dim == 128 and self.fuse_blocks and self.mfma_attention and self.bf16_tokens
                 and self.depth <= hip.UPDATER_MAX_DEPTH and hip.COMPOSITE and os.environ.get("MVT_COMPOSITE", "1") != "0")
+
+    def _composite_encoder_ok(self):
+        """mvt_encoder_forward covers bf16 mode with bf16 activations and the fused InstanceNorm path."""
+        return (self.precision == "bf16" and self.bf16_activations and self.fuse_norm and self.latent_dim % 32 == 0 and hip.COMPOSITE
+                and self.composite_encoder)
 
     def _updater_struct(self, pk, sd, matrix):
         """mvt_updater_weights (host struct of device pointers into ``pk``) for mvt_updateformer_forward."""
@@ -432,6 +449,9 @@ class MVTracker(nn.Module):
     def _encode(self, pk, x4, n, H, W, out_rows):
         """x4 (n,H,W,4) normalised RGB -> writes (n, H/4, W/4, C) into ``out_rows``."""
         C = self.latent_dim
+        if "encoder_struct" in pk and out_rows.is_contiguous():  # the whole CNN as ONE library call (mvt_encoder_forward)
+            ws = self._workspace(hip.encoder_workspace_bytes(n, H, W, C), x4.device)
+            return hip.encoder_forward(pk["encoder_struct"], x4, n, H, W, out_rows, C, ws, background=self._background)
         hs, ws = H // self.stride, W // self.stride
         x, h, w, st = self._conv(pk, "fnet.conv1", x4, n, H, W, 4, 64, 7, 2, 3, stats=True)
         lazy_stem = self.fuse_norm and self.precision == "bf16"  # relu(IN(stem)) is applied by its two consumers instead

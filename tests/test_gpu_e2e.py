@@ -653,3 +653,29 @@ def test_in_kernel_token_assembly_bit_identical(model):
             model.fuse_tokens = old
     model.check_finite()
     assert torch.equal(t1, r2["traj_e"]) and torch.equal(v1, r2["vis_e"])
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 96), (2, 180, 320)])
+def test_composite_encoder_bit_identical(model, shape):
+    """mvt_encoder_forward (the CNN's 56 launches sequenced inside the library over a caller workspace) against the same kernels
+    sequenced from Python: identical features, bit for bit (bf16 mode; also an odd-sized pyramid: 90x160 -> 45x80 -> 23x40 -> 12x20)."""
+    n, H, W = shape
+    x4 = torch.zeros(n, H, W, 4)
+    x4[..., :3] = torch.rand(n, H, W, 3, generator=torch.Generator().manual_seed(H)) * 2 - 1
+    x4 = x4.to(DEV)
+    outs = []
+    with _with_precision(model, "bf16"):
+        old = model.composite_encoder
+        try:
+            for comp in (True, False):
+                model.composite_encoder = comp
+                pk = model._pack(torch.device(DEV))
+                assert ("encoder_struct" in pk) == comp
+                o = torch.zeros(n, H // 4, W // 4, 128, device=DEV, dtype=torch.bfloat16)
+                model._encode(pk, x4, n, H, W, o)
+                outs.append(o)
+            torch.cuda.synchronize()
+        finally:
+            model.composite_encoder = old
+    assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0
+    assert torch.equal(outs[0], outs[1])
