@@ -310,6 +310,12 @@ typedef struct mvt_knn_level {
 int mvt_knn_scan_levels(int levels, const mvt_knn_level* lv, const float* coords, int N, int S, int frame0, int frame_step,
                         int T, int K, int seed_k, void* stream);
 int mvt_knn_merge_levels(int levels, const mvt_knn_level* lv, int N, int S, int K, void* stream);
+/* Seeded scan + merge of all levels in ONE launch: every (track, slot) is searched by a single wave over the whole cloud
+ * (tile boxes required; nseg and keys are ignored) and its K neighbour indices go straight to idx_out -- the result of
+ * mvt_knn_scan_levels + mvt_knn_merge_levels, bit for bit (exact kNN, ties by index).  idx_out may alias seed_idx: a wave reads
+ * the seeds of its own entries before it writes them.  seed_k >= K. */
+int mvt_knn_search_levels(int levels, const mvt_knn_level* lv, const float* coords, int N, int S, int frame0, int frame_step,
+                          int T, int K, int seed_k, void* stream);
 /* Gather-dot correlation for `levels` pyramid levels in ONE launch (grid.y = level).  Host arrays of per-level
  * DEVICE pointers: xyz[l] [T][P_l][4], fvec[l] [T][P_l][C] (C in {32,64,128,256}, groups == 1), idx[l]
  * [N][S][K] int32 from mvt_knn_merge, P[l].  For k < K:

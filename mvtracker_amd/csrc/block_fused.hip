@@ -44,6 +44,25 @@ template <int NMB> struct Cfg {
 constexpr int YLD = 40;   // bf16 row stride of the projection staging tile (32 columns + 8 pad)
 constexpr int FS = 512;   // elements per (32-row block, k-step) weight fragment: [64 lanes][8 bf16], see mvt_pack_frag_bf16
 
+// Diagnostic build only (-DMVT_STAMPS, tools/stamp_block.py): s_memtime at the phase boundaries of workgroups 0 and 100, one
+// slot per (workgroup, wave, stamp), in a buffer of its own.  No stamp executes in the shipped library.
+#ifdef MVT_STAMPS
+__device__ unsigned long long mvt_stamp_buf[2 * 8 * 64];
+#define STAMP(i)                                                                                                  \
+  do {                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    unsigned long long t_;                                                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && blockIdx.y == 0 && blockIdx.z == 0)                \
+      mvt_stamp_buf[((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + (i)] = t_;                                           \
+  } while (0)
+#else
+#define STAMP(i) \
+  do {           \
+  } while (0)
+#endif
+
 struct BlockArgs {
   float* x;                  // [M][ldx] tokens, updated in place
   int ldx;
@@ -106,6 +125,24 @@ __device__ __forceinline__ float token_elem(const BlockArgs& p, long long row, i
     v = p.t_maskvis[row * 2 + (d - 3 * E - 3 - Fc - Cf)];
   }
   return (v + p.t_pos[(long long)n * p.t_D + d]) + p.t_time[(long long)sidx * p.t_D + d];
+}
+
+// gelu_tanh on a pair: x * sigmoid(2k), k = sqrt(2/pi) (x + 0.044715 x^3), as x / (1 + exp2(x (c0 + c1 x^2))) with
+// c0 = -2 sqrt(2/pi) log2(e), c1 = 0.044715 c0.  Packed fp32 ops (v_pk_mul / v_pk_fma / v_pk_add) carry two values per
+// instruction; only v_exp_f32 / v_rcp_f32 are per value: ~26 instead of ~46 issue cycles per value -- the fc1 epilogue was VALU-bound
+// (in-kernel stamps: 3.2 k of the 8.7 k cycles of an MLP chunk).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_tanh_pk(f32x2 x) {
+  const f32x2 c0 = {-2.3022082f, -2.3022082f}, c1 = {-0.10294324f, -0.10294324f}, one = {1.0f, 1.0f};
+  const f32x2 a = (x * x * c1 + c0) * x;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(a[0]);
+  e[1] = __builtin_amdgcn_exp2f(a[1]);
+  const f32x2 d = e + one;
+  f32x2 rc;
+  rc[0] = __builtin_amdgcn_rcpf(d[0]);
+  rc[1] = __builtin_amdgcn_rcpf(d[1]);
+  return x * rc;
 }
 
 __device__ __forceinline__ bf16x8 ldg_frag(const unsigned short* p) {
@@ -195,6 +232,46 @@ __device__ __forceinline__ void gemm_wq(f32x16 (&acc)[NMB], bf16x8 (&wq)[PFQ], c
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[i], 0, 0, 0);
 #endif
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < KS / GK) {
+#pragma unroll
+      for (int j = 0; j < GK; ++j)
+#pragma unroll
+        for (int i = 0; i < NMB; ++i) xa[j][i] = xn[j][i];
+    }
+  }
+}
+// The attention output projection (Ko = 288: 18 k-steps) on the same queue: fragments 0..15 in wq -- requested long
+// before (ahead of / inside the attention phase), so the projection starts on resident operands instead of paying a memory round
+// trip per four k-steps -- and, with REFILL, the queue leaves holding the first 16 fragments of the stream nxt (the MLP's fc1).
+template <int NMB, bool REFILL>
+__device__ __forceinline__ void gemm_wq18(f32x16 (&acc)[NMB], bf16x8 (&wq)[PFQ], const unsigned short* wrow, const unsigned short* nxt,
+                                          const unsigned short* arow, int lda) {
+  constexpr int KS = 18, GK = 2;
+  // (the last two fragments are requested here: sixteen k-steps of MFMAs pass before they are needed)
+  const bf16x8 wx[2] = {ldg_frag(wrow + 16 * FS), ldg_frag(wrow + 17 * FS)};
+  bf16x8 xa[GK][NMB], xn[GK][NMB];
+#pragma unroll
+  for (int j = 0; j < GK; ++j)
+#pragma unroll
+    for (int i = 0; i < NMB; ++i) xa[j][i] = lds_frag(arow + i * 32 * lda + j * 16);
+#pragma unroll
+  for (int g = 0; g < KS / GK; ++g) {
+    if (g + 1 < KS / GK) {
+#pragma unroll
+      for (int j = 0; j < GK; ++j)
+#pragma unroll
+        for (int i = 0; i < NMB; ++i) xn[j][i] = lds_frag(arow + i * 32 * lda + ((g + 1) * GK + j) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < GK; ++j) {
+      const int ks = g * GK + j;
+      const bf16x8 wa = ks < PFQ ? wq[ks < PFQ ? ks : 0] : wx[ks >= PFQ ? ks - PFQ : 0];
+      if (REFILL && ks < PFQ) wq[ks] = ldg_frag(nxt + ks * FS);
+#pragma unroll
+      for (int i = 0; i < NMB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xa[j][i], acc[i], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (g + 1 < KS / GK) {
@@ -310,6 +387,10 @@ __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int 
       for (int e = 0; e < 16; ++e) sc[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[mb][ks], sc, 0, 0, 0);
+      // keys 16.. of this block (accumulator registers 8..15, the second PV k-step) do not exist when nk <= kb*32 + 16 -- the time
+      // attention's S = 12: their scores are -inf, their probabilities exactly 0 and their PV products add +0, so leaving them out
+      // (wave-uniform branch) changes no bit of the result and saves half of the exponentials and PV MFMAs
+      const bool half = nk <= kb * 32 + 16;
       float mx = -INFINITY;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -322,9 +403,16 @@ __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int 
       const float corr = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
       float ps = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < 8; ++e) {
         sc[e] = __expf(sc[e] - mn);
         ps += sc[e];
+      }
+      if (!half) {
+#pragma unroll
+        for (int e = 8; e < 16; ++e) {
+          sc[e] = __expf(sc[e] - mn);
+          ps += sc[e];
+        }
       }
       l[mb] = l[mb] * corr + ps;
       m[mb] = mn;
@@ -336,6 +424,7 @@ __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int 
       }
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
+        if (sk == 1 && half) break;
         f32x4 lo4, hi4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -388,6 +477,16 @@ __device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short
                                           const float* lnw, const float* lnb) {
   constexpr int BM = 32 * NMB;
   const int r = lane & 31, h = lane >> 5;
+  // the affine parameters of this wave's channel slice are requested first: their memory round trip passes under the statistics
+  // exchange and its barrier (read after it, they cost a LayerNorm with affine twice the time of one without)
+  f32x4 gw[4], gb[4];
+  if (lnw) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      gw[g] = *reinterpret_cast<const f32x4*>(lnw + wave * 32 + 8 * g + 4 * h);
+      gb[g] = *reinterpret_cast<const f32x4*>(lnb + wave * 32 + 8 * g + 4 * h);
+    }
+  }
 #pragma unroll
   for (int mb = 0; mb < NMB; ++mb) {
     float s1 = 0.f, s2 = 0.f;
@@ -421,7 +520,7 @@ __device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         o[e] = (v[mb][4 * g + e] - mean) * rstd;
-        if (lnw) o[e] = o[e] * lnw[n + e] + lnb[n + e];
+        if (lnw) o[e] = o[e] * gw[g][e] + gb[g][e];
       }
       const bf16x4 b = __builtin_convertvector(o, bf16x4);
       *reinterpret_cast<u32x2*>(&Xs[(mb * 32 + r) * LDX + n]) = __builtin_bit_cast(u32x2, b);
@@ -449,7 +548,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned short Xs[BM * LDX];
   __shared__ __attribute__((aligned(16))) unsigned short Hs[2][BM * LDH];
   __shared__ float st[8 * BM * 2];
-  __shared__ float b1s[4 * C];
+  __shared__ __attribute__((aligned(16))) float b1s[4 * C];
 
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
@@ -483,8 +582,18 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   // the token / attention-operand loads and the LayerNorm instead of following them.
   constexpr bool EARLY = NMB == 1 && MODE != 0;
   bool early_have = false;
-  if (EARLY && MODE == 1) {
-    fill_wq(wq, p.w1 + ((long long)(wave % K_::JW) * (C / 16) * 64 + lane) * 8 + (long long)blockIdx.y * K_::JW * (C / 16) * FS);
+  // The attention output projection (every form but pass 2 and the input transform, when there is an attention) takes its 18
+  // weight fragments from the queue too (gemm_wq18): they are requested ahead of / inside the attention phase and the queue is
+  // refilled with the first fc1 fragments while the projection runs, so neither GEMM starts on a memory round trip.
+  const bool outp = MODE != 2 && ATT != 4 && (ATT != 0 || p.att != nullptr);
+  const unsigned short* wo_row = p.wo + ((long long)wave * 18 * 64 + lane) * 8;
+  const unsigned short* fc1_first = p.w1 + ((long long)(wave % K_::JW) * (C / 16) * 64 + lane) * 8 +
+                                    (long long)(MODE == 1 ? (int)blockIdx.y : 0) * K_::JW * (C / 16) * FS;
+  auto prefetch_wo = [&]() { fill_wq(wq, wo_row); };
+  if (HAS_MLP && !outp) {
+    fill_wq(wq, fc1_first);
+  } else if (outp && ATT != 1) {
+    prefetch_wo();  // (time attention: after the second unit, when its operand registers are free -- see below)
   } else if (EARLY && MODE == 2) {
     const int nb0e = (int)blockIdx.y * 8 + wave;
     if (active(0) && nb0e < (p.next[0].N + 31) / 32) {
@@ -493,12 +602,26 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     }
   }
 
+  STAMP(0);
   // token values of this wave's 32-channel slice: v[mb][e] = x[m0 + mb*32 + r][wave*32 + (e&3) + 8*(e>>2) + 4h]
   f32x16 v[NMB];
 #pragma unroll
   for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[mb][e] = 0.f;
+
+  // the tile's own x rows (added after the projection) are requested BEFORE the projection GEMM, which hides their round trip
+  f32x4 xr[NMB][4];
+  auto load_x = [&]() {
+    if (ATT == 4 || (MODE == 2 && p.ws)) return;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const long long m = grow(mb * 32 + r);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        xr[mb][g] = m >= 0 ? *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
 
   // ---- 1. attention output projection (accumulated into v, x is added afterwards)
   if (MODE == 3 && ATT == 4) {
@@ -602,7 +725,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
     }
     __syncthreads();
-    gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);
+    load_x();
+    gemm_wq18<NMB, HAS_MLP>(v, wq, wo_row, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
@@ -617,6 +741,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     unsigned short* vt = wave < XW ? &Xs[wave * VTA] : &Hs[0][0] + ((BM * LDA + 7) & ~7) + (wave - XW) * VTA;
     static_assert(XW + (2 * BM * LDH - BM * LDA - 8) / VTA >= 6, "six V^T images fit beside the attention tile");
     __syncthreads();
+    STAMP(1);
     if (ATT == 1) {
       // units (track, head) are dealt round-robin to the waves; the operands of ALL of a wave's units are fetched first (one
       // exposed memory latency instead of one per unit), then the units are computed back to back
@@ -640,8 +765,18 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
           const int u = u0 + 8 * i;
           const int tr = u / 6, hd = u - tr * 6;
           if (ok[i]) attn_compute<1, 1>(fr[i], p.S, p.S, hd, vt, zrow, As, LDA, tr * p.S, lane);
+          if (i == 2 && u0 == wave) {
+            // (not earlier: the operands of the pending units still occupy the registers; the empty asm keeps the sixteen fragment
+            //  addresses from being computed ahead of the loop and spilled)
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned short* wr = wo_row;
+            asm volatile("" : "+v"(wr));
+            fill_wq(wq, wr);
+            __builtin_amdgcn_sched_barrier(0);
+          }  // the operand registers of three units are free: the round trip passes under the last
         }
       }
+      if (ntr * 6 <= wave) prefetch_wo();  // (a wave without units)
     } else if (wave < 6 && grow(0) >= 0) {
       const long long left = ntok - (long long)blockIdx.x * BM;
       const int nq = left < BM ? (int)left : BM;
@@ -651,8 +786,11 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, lane);
       attn_compute<NMB, 2>(fr, nq, p.nkeys, wave, vt, zrow, As, LDA, 0, lane);
     }
+    STAMP(2);
     __syncthreads();
-    gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);
+    STAMP(3);
+    load_x();
+    gemm_wq18<NMB, HAS_MLP>(v, wq, wo_row, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
@@ -675,13 +813,19 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
       *reinterpret_cast<u32x2*>(&As[row * LDA + c]) = w;
     }
+    STAMP(2);
     __syncthreads();
-    gemm_wt<18, NMB>(v, p.wo + ((long long)wave * 18 * 64 + lane) * 8, &As[r * LDA + 8 * h], LDA, 0);
+    STAMP(3);
+    load_x();
+    gemm_wq18<NMB, HAS_MLP>(v, wq, wo_row, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[mb][e] += p.bo[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+  } else {
+    load_x();
   }
+  STAMP(4);
 #pragma unroll
   for (int mb = 0; mb < NMB; ++mb) {
     if (ATT == 4) break;  // (x was just computed)
@@ -701,8 +845,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) xv[e] += p.b2[wave * 32 + 8 * g + 4 * h + e];
-      } else if (m >= 0) {  // (MODE 2 without a workspace = mvt_ln_proj_bf16: x is final and only read; ws / b2 are null there)
-        xv = *reinterpret_cast<const f32x4*>(p.x + m * (long long)p.ldx + wave * 32 + 8 * g + 4 * h);
+      } else {  // (MODE 2 without a workspace = mvt_ln_proj_bf16: x is final and only read; ws / b2 are null there)
+        xv = xr[mb][g];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += xv[e];
@@ -726,7 +870,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
     }
   };
+  STAMP(5);
   if (HAS_MLP) ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
+  STAMP(6);
   const bool tail_next = MODE == 0 && active(0) && wave < (p.next[0].N + 31) / 32;
   if (HAS_MLP) {
     f32x16 acc2[NMB];
@@ -745,7 +891,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     // k-steps each, so the queue always holds the next 16 fragments of that sequence (>= 16 MFMA k-steps of lookahead,
     // which is what an L2 round trip needs; two half-depth queues left every fragment ~250 cycles short)
     const int c_lo = MODE == 1 ? (int)blockIdx.y : 0, c_hi = MODE == 1 ? c_lo + 1 : nchunk;
-    if (!(EARLY && MODE == 1)) fill_wq(wq, w1row + (long long)c_lo * JW * (C / 16) * FS);
+    // (the queue already holds fc1(c_lo): filled at kernel start, or by the output projection while it ran)
 #pragma unroll 1
     for (int c = c_lo; c < c_hi; ++c) {
       unsigned short* Hb = Hs[c & 1];
@@ -755,28 +901,39 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       for (int i = 0; i < NM1; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ha[i][e] = 0.f;
+      STAMP(8 + 5 * c);
       gemm_wq<C / 16, NM1>(ha, wq, w1row + (long long)c * JW * (C / 16) * FS, w2row + (long long)c * (HC / 16) * FS, &Xs[r * LDX + 8 * h], LDX,
                            NM1 * mp);
+      STAMP(9 + 5 * c);
 #pragma unroll
       for (int i = 0; i < NM1; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(&b1s[c * HC + jb * 32 + 8 * g + 4 * h]);
           f32x4 o;
-#pragma unroll
 #ifdef MVT_ABL_NOGELU
-          for (int e = 0; e < 4; ++e) o[e] = ha[i][4 * g + e] + b1s[c * HC + jb * 32 + 8 * g + 4 * h + e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = ha[i][4 * g + e] + bq[e];
 #else
-          for (int e = 0; e < 4; ++e) o[e] = mvt_gelu_tanh(ha[i][4 * g + e] + b1s[c * HC + jb * 32 + 8 * g + 4 * h + e]);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const f32x2 y = gelu_tanh_pk((f32x2){ha[i][4 * g + e] + bq[e], ha[i][4 * g + e + 1] + bq[e + 1]});
+            o[e] = y[0];
+            o[e + 1] = y[1];
+          }
 #endif
           const bf16x4 b = __builtin_convertvector(o, bf16x4);
           *reinterpret_cast<u32x2*>(&Hb[((NM1 * mp + i) * 32 + r) * LDH + jb * 32 + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, b);
         }
       }
+      STAMP(10 + 5 * c);
       __syncthreads();
+      STAMP(11 + 5 * c);
       // fc2 partial: out^T block (channels of this wave) += W2[:, chunk] . H^T; refills the queue with the next chunk's fc1
       // fragments (after the last chunk: with the first follow-up projection's, or harmlessly with fc1(c0) again)
       const unsigned short* after = c + 1 < c_hi ? w1row + (long long)(c + 1) * JW * (C / 16) * FS : tail;
       gemm_wq<HC / 16, NMB>(acc2, wq, w2row + (long long)c * (HC / 16) * FS, after, &Hb[r * LDH + 8 * h], LDH, 0);
+      STAMP(12 + 5 * c);
     }
     if (MODE == 1) {  // partial fc2 output of this chunk (+ x after the projection, once) -> workspace; pass 2 finishes
 #pragma unroll
@@ -806,7 +963,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += acc2[mb][4 * g + e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
   }
+  STAMP(30);
   if (MODE == 0 || ATT == 4 || (p.ws && blockIdx.y == 0)) store_x();  // (never in the projection-only form: x is read-only there)
+  STAMP(31);
 
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
   bool have = tail_next || early_have;  // the queue already holds this wave's first block of the projection
@@ -819,7 +978,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     // the projection's bias goes through LDS (b1s is free after the MLP; N <= 4C): a global load in the epilogue would sit
     // behind the 16 queued fragment loads in the in-order vmcnt counter and expose their whole latency every block
     for (int i = t; i < nx.N; i += NT) b1s[i] = nx.b[i];
+    STAMP(32 + 8 * q);
     ln_to_lds<NMB>(v, Xs, st, wave, lane, nx.eps, nx.lnw, nx.lnb);
+    STAMP(33 + 8 * q);
     const int nblocks = (nx.N + 31) / 32;
     auto nrow_of = [&](int nb) { return nx.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
     const int nb0 = MODE == 2 ? (int)blockIdx.y * 8 + wave : wave, nbstep = MODE == 2 ? 8 * (int)gridDim.y : 8;
@@ -837,6 +998,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
       gemm_wq<C / 16, NMB>(acc, wq, nrow_of(nb), nb + nbstep < nblocks ? nrow_of(nb + nbstep) : (chain ? chain : nrow_of(nb)), &Xs[r * LDX + 8 * h], LDX, 0);
+      STAMP(34 + 8 * q + (nb - nb0) / nbstep);
       if (nx.y_bf16 && nb * 32 + 31 < nx.N && (nx.ldy & 7) == 0 && ((uintptr_t)nx.y & 15) == 0) {
         // bf16 projection output through a wave-private LDS tile (the H buffers are idle now): the accumulator layout (token on
         // the lane) stores 8 bytes per lane into 32 different rows; staged, every lane stores 16 bytes and a row's 32 columns
@@ -883,7 +1045,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
       }
     }
+    STAMP(39 + 8 * q);
   }
+  STAMP(63);
 }
 
 // [N][ld] row-major bf16 -> fragment-major [ceil(N/32)][K/16][64 lanes][8]: lane (r = l&31, h = l>>5) of fragment
@@ -904,6 +1068,16 @@ __global__ void pack_frag_kernel(const unsigned short* __restrict__ w, int ld, i
 }
 
 }  // namespace
+
+#ifdef MVT_STAMPS
+extern "C" int mvt_debug_read_stamps(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(mvt_stamp_buf), sizeof(unsigned long long) * 2 * 8 * 64) == hipSuccess ? MVT_OK : MVT_ERR_HIP_BASE;
+}
+extern "C" int mvt_debug_clear_stamps() {
+  static unsigned long long z[2 * 8 * 64];
+  return hipMemcpyToSymbol(HIP_SYMBOL(mvt_stamp_buf), z, sizeof(z)) == hipSuccess ? MVT_OK : MVT_ERR_HIP_BASE;
+}
+#endif
 
 extern "C" int mvt_pack_frag_bf16(const unsigned short* w, int ld, int N, int K, unsigned short* out, void* stream) {
   MVT_REQUIRE(w && out && N > 0 && K > 0 && K % 16 == 0 && ld % 8 == 0 && ld >= K);
@@ -930,7 +1104,7 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const void* att, int att_
     const mvt_block_next& nx = next[q];
     MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
     MVT_REQUIRE(nx.y_bf16 == 0 || nx.y_bf16 == 1);
-    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.lnw % 16 == 0) && ((uintptr_t)nx.lnb % 16 == 0) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
     MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo));
     a.next[q] = nx;
     if (nx.row_hi == 0) a.next[q].row_hi = M;
@@ -973,7 +1147,7 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
   for (int q = 0; q < n_next; ++q) {
     const mvt_block_next& nx = next[q];
     MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
-    MVT_REQUIRE((nx.y_bf16 == 0 || nx.y_bf16 == 1) && (nx.lnw == nullptr) == (nx.lnb == nullptr));
+    MVT_REQUIRE((nx.y_bf16 == 0 || nx.y_bf16 == 1) && (nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.lnw % 16 == 0) && ((uintptr_t)nx.lnb % 16 == 0));
     MVT_REQUIRE(((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0) && nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo));
     a.next[q] = nx;
     if (nx.row_hi == 0) a.next[q].row_hi = M;
@@ -1032,7 +1206,7 @@ extern "C" int mvt_input_proj_bf16(const float* tokens, int ldtok, int token_dim
   for (int q = 0; q < n_next; ++q) {
     const mvt_block_next& nx = next[q];
     MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
-    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.lnw % 16 == 0) && ((uintptr_t)nx.lnb % 16 == 0) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
     MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo) && (nx.y_bf16 == 0 || nx.y_bf16 == 1));
     a.next[q] = nx;
     if (nx.row_hi == 0) a.next[q].row_hi = M;
@@ -1060,7 +1234,7 @@ extern "C" int mvt_token_input_proj_bf16(const float* coords, const float* fcorr
   for (int q = 0; q < n_next; ++q) {
     const mvt_block_next& nx = next[q];
     MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
-    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.lnw % 16 == 0) && ((uintptr_t)nx.lnb % 16 == 0) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
     MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo) && (nx.y_bf16 == 0 || nx.y_bf16 == 1));
     a.next[q] = nx;
     if (nx.row_hi == 0) a.next[q].row_hi = M;
@@ -1080,7 +1254,7 @@ extern "C" int mvt_ln_proj_bf16(const float* x, int ldx, const mvt_block_next* n
   for (int q = 0; q < n_next; ++q) {
     const mvt_block_next& nx = next[q];
     MVT_REQUIRE(nx.w && nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N);
-    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
+    MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.lnw % 16 == 0) && ((uintptr_t)nx.lnb % 16 == 0) && ((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0));
     MVT_REQUIRE(nx.row_lo >= 0 && (nx.row_hi == 0 || nx.row_hi > nx.row_lo) && (nx.y_bf16 == 0 || nx.y_bf16 == 1));
     a.next[q] = nx;
     if (nx.row_hi == 0) a.next[q].row_hi = M;

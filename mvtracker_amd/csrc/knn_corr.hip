@@ -160,7 +160,8 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
                                               const float* __restrict__ coords, int N, int S, int frame0, int frame_step, int T, int K,
                                               int nseg, unsigned long long* __restrict__ keys, int qgroups,
                                               const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch, int seed_fw,
-                                              int seed_fh, const float* __restrict__ box, int grid_w, int grid_h) {
+                                              int seed_fh, const float* __restrict__ box, int grid_w, int grid_h,
+                                              int* __restrict__ idx_direct = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // task id -> (segment, query group, slot); segment fastest so that heavy frames spread over CUs
   long long task = (long long)blockIdx.x * 4 + wave;
@@ -331,7 +332,15 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
       select_k(l, nc, K, lane);
       v = lane < K ? l[lane] : KEY_MAX;
     }
-    if (n < N && lane < K) keys[(((long long)n * S + s) * nseg + seg) * K + lane] = v;
+    if (n < N && lane < K) {
+      if (idx_direct) {  // single segment: the sorted list IS the result (mvt_knn_merge's index extraction and clamp)
+        unsigned id = (unsigned)v;
+        if ((long long)id >= P) id = (unsigned)(P - 1);
+        idx_direct[((long long)n * S + s) * K + lane] = (int)id;
+      } else {
+        keys[(((long long)n * S + s) * nseg + seg) * K + lane] = v;
+      }
+    }
   }
 }
 
@@ -359,6 +368,17 @@ __global__ __launch_bounds__(256) void knn_scan_levels_kernel(KnnLevels a, const
   const mvt_knn_level L = a.lv[blockIdx.y];
   knn_scan_body<Q>(lds, L.xyz, L.P, coords, N, S, frame0, frame_step, T, K, L.nseg, L.keys, qgroups, L.seed_idx, seed_k, 0, 0, 0, 0,
                    L.tile_box, L.grid_w, L.grid_h);
+}
+
+// Seeded search of all levels, single segment, neighbour indices written directly (no key lists, no merge launch).  A wave reads
+// the seeds of its own (track, slot) entries before it writes them, so idx_out may alias seed_idx.
+template <int Q>
+__global__ __launch_bounds__(256) void knn_search_levels_kernel(KnnLevels a, const float* __restrict__ coords, int N, int S, int frame0,
+                                                                int frame_step, int T, int K, int qgroups, int seed_k) {
+  __shared__ unsigned long long lds[4 * Q * CAP];
+  const mvt_knn_level L = a.lv[blockIdx.y];
+  knn_scan_body<Q>(lds, L.xyz, L.P, coords, N, S, frame0, frame_step, T, K, 1, nullptr, qgroups, L.seed_idx, seed_k, 0, 0, 0, 0, L.tile_box,
+                   L.grid_w, L.grid_h, L.idx_out);
 }
 
 // Merge the nseg per-segment lists of one (track, slot) into its K nearest neighbour indices.  Every lane holds
@@ -649,6 +669,36 @@ extern "C" int mvt_knn_merge_levels(int levels, const mvt_knn_level* lv, int N, 
   const long long rows = (long long)N * S;
   hipLaunchKernelGGL(knn_merge_levels_kernel, dim3((unsigned)mvt_cdiv(rows, 4), (unsigned)levels), dim3(256), 0, mvt_stream(stream), a,
                      rows, K);
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_knn_search_levels(int levels, const mvt_knn_level* lv, const float* coords, int N, int S, int frame0, int frame_step,
+                                     int T, int K, int seed_k, void* stream) {
+  MVT_REQUIRE(levels >= 1 && levels <= 8 && lv && coords && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0);
+  MVT_REQUIRE(K >= 1 && K <= 16 && seed_k >= K && seed_k <= 64);
+  KnnLevels a{};
+  for (int l = 0; l < levels; ++l) {
+    const mvt_knn_level& L = lv[l];
+    MVT_REQUIRE(L.xyz && L.seed_idx && L.idx_out && L.tile_box && L.P >= K && L.P < (1LL << 31));
+    MVT_REQUIRE((L.grid_w == 0 && L.grid_h == 0) ||
+                (L.grid_w > 0 && L.grid_h > 0 && L.grid_w % 8 == 0 && L.grid_h % 8 == 0 && L.P % ((long long)L.grid_w * L.grid_h) == 0));
+    a.lv[l] = L;
+  }
+  static const int q_env = getenv("MVT_KNN_Q") ? atoi(getenv("MVT_KNN_Q")) : 0;
+  const int Q = q_env ? q_env : 2;
+  const int qgroups = (N + Q - 1) / Q;
+  const dim3 grid((unsigned)mvt_cdiv((long long)qgroups * S, 4), (unsigned)levels);
+#define LAUNCH(QQ)                                                                                                                \
+  hipLaunchKernelGGL((knn_search_levels_kernel<QQ>), grid, dim3(256), 0, mvt_stream(stream), a, coords, N, S, frame0, frame_step, T, K, \
+                     qgroups, seed_k)
+  switch (Q) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    default: return MVT_ERR_ARG;
+  }
+#undef LAUNCH
   return mvt_launch_status();
 }
 

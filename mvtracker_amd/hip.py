@@ -61,6 +61,7 @@ SIGNATURES = {
     "mvt_input_proj_bf16": [P, I, I, LL, P, P, P, I, P, I, P, I, LL, I, P],
     "mvt_adapter_best_view": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mvt_knn_scan_levels": [I, P, P, I, I, I, I, I, I, I, P],
+    "mvt_knn_search_levels": [I, P, P, I, I, I, I, I, I, I, P],
     "mvt_knn_merge_levels": [I, P, I, I, I, P],
     "mvt_corr_gather_dot": [I, P, P, I, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
     "mvt_knn1_gather": [P, I, LL, I, P, I, I, I, P, P, P],
@@ -383,6 +384,12 @@ def knn_scan_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k=0):
     """levels: list of dicts(xyz, P, keys, nseg[, seed_idx, box, grid, idx_out]); one launch for all of them."""
     arr = _knn_levels(levels)
     _call("mvt_knn_scan_levels", len(levels), C.cast(arr, C.c_void_p), _ptr(coords), N, S, frame0, frame_step, T, K, seed_k, _stream())
+
+
+def knn_search_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k):
+    """Seeded scan + merge in one launch: levels of dicts(xyz, P, seed_idx, box, grid, idx_out); idx_out may alias seed_idx."""
+    arr = _knn_levels([dict(lv, keys=None, nseg=1) for lv in levels])
+    _call("mvt_knn_search_levels", len(levels), C.cast(arr, C.c_void_p), _ptr(coords), N, S, frame0, frame_step, T, K, seed_k, _stream())
 
 
 def knn_merge_levels(levels, N, S, K):

@@ -132,6 +132,7 @@ class MVTracker(nn.Module):
         # launch (all variants are bit-identical to the separate launches)
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
+        self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
         self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
         self.fuse_tokens = os.environ.get("MVT_FUSE_TOKENS", "1") != "0"  # ... with the token rows assembled inside that launch
         self.fuse_input = os.environ.get("MVT_FUSE_INPUT", "1") != "0"  # input transform + virtual tokens + first q|k|v in one launch
@@ -826,8 +827,11 @@ class MVTracker(nn.Module):
         for it in range(iters):
             if it > 0:
                 # every level is seeded by its own previous neighbours: the four scans are independent -> one launch
-                hip.knn_scan_levels(levels, coords, n, S, frame0, 1, T, K, seed_k=K)
-                hip.knn_merge_levels(levels, n, S, K)
+                if self.knn_one_launch:
+                    hip.knn_search_levels(levels, coords, n, S, frame0, 1, T, K, seed_k=K)
+                else:
+                    hip.knn_scan_levels(levels, coords, n, S, frame0, 1, T, K, seed_k=K)
+                    hip.knn_merge_levels(levels, n, S, K)
             else:
                 n0 = 0
                 if carry is not None and carry[1] > 0 and self.seed_across_windows:
@@ -839,8 +843,11 @@ class MVTracker(nn.Module):
                     slot = torch.tensor([min(s_ + S // 2, S - 1) for s_ in range(S)], device=dev)
                     seed_t = prev_idx[:, :n0].index_select(2, slot).contiguous()
                     lv0 = [dict(lv, keys=keys[l_][:n0 * S * nsegs[l_] * K], seed_idx=seed_t[l_], idx_out=idx[l_][:n0]) for l_, lv in enumerate(levels)]
-                    hip.knn_scan_levels(lv0, coords, n0, S, frame0, 1, T, K, seed_k=K)
-                    hip.knn_merge_levels(lv0, n0, S, K)
+                    if self.knn_one_launch:
+                        hip.knn_search_levels(lv0, coords, n0, S, frame0, 1, T, K, seed_k=K)
+                    else:
+                        hip.knn_scan_levels(lv0, coords, n0, S, frame0, 1, T, K, seed_k=K)
+                        hip.knn_merge_levels(lv0, n0, S, K)
                 if n0 < n:  # new tracks: coarse to fine, level l+1's neighbours bound level l's first scan
                     m = n - n0
                     for lvl in reversed(range(L)):

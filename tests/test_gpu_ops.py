@@ -697,6 +697,13 @@ def test_knn_levels_one_launch(hip):
     torch.cuda.synchronize()
     for a, b in zip(ref2, got2):
         assert torch.equal(a, b)
+    # mvt_knn_search_levels: scan + merge in one launch, one wave per (track, slot), IN PLACE (idx_out aliases seed_idx)
+    inpl = [r.clone() for r in ref]
+    lv = [dict(xyz=clouds[l], P=V * h * w, seed_idx=inpl[l], box=boxes[l], grid=(w, h), idx_out=inpl[l]) for l, (h, w) in enumerate(grids)]
+    hip.knn_search_levels(lv, q, M, B, 0, 1, B, K, seed_k=K)
+    torch.cuda.synchronize()
+    for a, b in zip(ref2, inpl):
+        assert torch.equal(a, b)
 
 
 def test_corr_all_levels_one_launch(hip):
