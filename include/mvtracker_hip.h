@@ -287,6 +287,10 @@ int mvt_unproject(const float* depth_s, const float* kinv, const float* einv, fl
 int mvt_tile_aabb(const float* xyz, long long P, int T, int grid_w, int grid_h,
                   float* box /* [T][ceil(P/64)][8] = lo.xyz, finite-point count, hi.xyz, 0 */,
                   void* stream);
+/* Coarse level of the culling hierarchy: group_box [T][ceil(ntiles/64)][8] = the union of the boxes of 64 consecutive tiles
+ * (same record layout).  Used by the single-segment searches below (clouds of 65..4096 tiles), which test the group boxes first
+ * and skip whole runs of tiles; exactness is unaffected (a group box contains its tiles' boxes). */
+int mvt_tile_group_aabb(const float* box, long long P, int T, float* group_box, void* stream);
 int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step,
                  int T, int K, int nseg, unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw,
                  int seed_ch, int seed_fw, int seed_fh, const float* tile_box, int grid_w, int grid_h, void* stream);
@@ -294,6 +298,13 @@ int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int 
  * indices, ascending by (d2, index); indices are clamped to [0, P) (only NaN queries can be out of range). */
 int mvt_knn_merge(const unsigned long long* keys, int N, int S, int K, int nseg, long long P, int* idx_out,
                   void* stream);
+/* mvt_knn_scan (one segment) + mvt_knn_merge in ONE launch: every (track, slot) is searched by a single wave over the whole cloud
+ * and its K neighbour indices go straight to idx_out [N][S][K] -- bit for bit the merged result of the two-launch form.  tile_box
+ * required, group_box optional; seeds as in mvt_knn_scan (NULL: unseeded).  idx_out must not alias seed_idx when the seed comes
+ * from another level (seed_cw > 0 reads other entries' indices only of the coarser tensor, never of idx_out). */
+int mvt_knn_search(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step, int T, int K,
+                   const int* seed_idx, int seed_k, int seed_cw, int seed_ch, int seed_fw, int seed_fh, const float* tile_box,
+                   const float* group_box, int grid_w, int grid_h, int* idx_out, void* stream);
 /* Scan / merge of several pyramid levels in ONE launch each (grid.y = level).  After the first refinement iteration every
  * level is seeded by its own previous neighbours (seed_idx [N][S][seed_k], same-level indices), so the scans are
  * independent; one launch removes three launch / tail latencies per iteration.  Semantics per level = mvt_knn_scan /
@@ -306,6 +317,7 @@ typedef struct mvt_knn_level {
   const float* tile_box;    /* from mvt_tile_aabb(grid_w, grid_h) or NULL */
   int nseg, grid_w, grid_h;
   int* idx_out;             /* [N][S][K] (merge) */
+  const float* group_box;   /* from mvt_tile_group_aabb or NULL: coarse culling level of mvt_knn_search_levels */
 } mvt_knn_level;
 int mvt_knn_scan_levels(int levels, const mvt_knn_level* lv, const float* coords, int N, int S, int frame0, int frame_step,
                         int T, int K, int seed_k, void* stream);

@@ -95,29 +95,25 @@ __device__ __forceinline__ unsigned long long rank_sort(const unsigned long long
                                   (unsigned)__builtin_amdgcn_readlane((int)lo, j);
     rank += ej < e ? 1 : 0;
   }
-  // lane r fetches the key whose rank is r: ranks are a permutation of 0..cnt-1 (keys are unique)
-  unsigned long long out = KEY_MAX;
-#pragma unroll 1
-  for (int j = 0; j < cnt; ++j) {
-    const int rj = __builtin_amdgcn_readlane(rank, j);
-    const unsigned long long ej = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) |
-                                  (unsigned)__builtin_amdgcn_readlane((int)lo, j);
-    if (rj == lane) out = ej;
-  }
-  return out;
+  // lane r receives the key whose rank is r: ranks of the cnt live lanes are a permutation of 0..cnt-1 (keys are unique), so the
+  // forward permute (every lane pushes its key to lane `rank`) has one writer per destination below cnt; the idle lanes (rank =
+  // cnt, key KEY_MAX) all push to lane cnt, harmlessly.  Two ds_permute instead of a 64-iteration readlane loop.
+  const unsigned plo = (unsigned)__builtin_amdgcn_ds_permute(rank * 4, (int)lo), phi = (unsigned)__builtin_amdgcn_ds_permute(rank * 4, (int)hi);
+  return lane < cnt ? (((unsigned long long)phi << 32) | plo) : KEY_MAX;
 }
 
 // Candidate tiles.  The scan visits the cloud 64 points (one wave load) at a time:
 //   linear tiles (grid_w == 0): tile t = points [64 t, 64 t + 64);
 //   patch tiles  (grid_w  > 0): the cloud is V images of grid_h x grid_w points in raster order (both multiples of 8) and
 //                               tile t is an 8x8 pixel patch - eight 128-byte row pieces - whose bounding box is compact.
-__device__ __forceinline__ long long tile_point(long long tile, int lane, int grid_w, int grid_h) {
+// (32-bit arithmetic: P < 2^31 is required by every caller, and a 64-bit division per visited tile cost more than the tile's compares)
+__device__ __forceinline__ int tile_point(int tile, int lane, int grid_w, int grid_h) {
   if (grid_w == 0) return tile * 64 + lane;
-  const int tpr = grid_w >> 3, tpv = tpr * (grid_h >> 3);
-  const long long v = tile / tpv;
-  const int r = (int)(tile - v * tpv);
-  const int ty = r / tpr, tx = r - ty * tpr;
-  return (v * grid_h + ty * 8 + (lane >> 3)) * grid_w + tx * 8 + (lane & 7);
+  const unsigned tpr = (unsigned)grid_w >> 3, tpv = tpr * ((unsigned)grid_h >> 3);
+  const unsigned v = (unsigned)tile / tpv;
+  const unsigned r = (unsigned)tile - v * tpv;
+  const unsigned ty = r / tpr, tx = r - ty * tpr;
+  return (int)((v * grid_h + ty * 8 + (lane >> 3)) * grid_w + tx * 8 + (lane & 7));
 }
 
 // box[frame][tile] = {lo.xyz, number of finite points, hi.xyz, 0}; NaN points are ignored (fminf / fmaxf drop them), an all-NaN tile gets lo = +inf, hi = -inf
@@ -127,7 +123,7 @@ __global__ __launch_bounds__(256) void tile_aabb_kernel(const float* __restrict_
   const long long id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // frame * ntiles + tile
   if (id >= total) return;
   const long long frame = id / ntiles, tile = id - frame * ntiles;
-  const long long c = tile_point(tile, lane, grid_w, grid_h);
+  const long long c = tile_point((int)tile, lane, grid_w, grid_h);
   const float inf = __int_as_float(0x7f800000);
   float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
   bool finite = false;
@@ -155,28 +151,65 @@ __global__ __launch_bounds__(256) void tile_aabb_kernel(const float* __restrict_
   }
 }
 
+// gbox[frame][g] = the union of the boxes of tiles [64 g, 64 g + 64) (same record layout; .w = their finite points): the coarse
+// level of the culling hierarchy -- a single-segment search tests these first and skips whole runs of 64 tiles.
+__global__ __launch_bounds__(256) void tile_group_aabb_kernel(const float* __restrict__ box, long long ntiles, long long ngroups,
+                                                              long long total, float* __restrict__ gbox) {
+  const int lane = threadIdx.x & 63;
+  const long long id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // frame * ngroups + group
+  if (id >= total) return;
+  const long long frame = id / ngroups, g = id - frame * ngroups;
+  const long long t = g * 64 + lane;
+  const float inf = __int_as_float(0x7f800000);
+  float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, cnt = 0.f;
+  if (t < ntiles) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(box + (frame * ntiles + t) * 8), b = *reinterpret_cast<const f32x4*>(box + (frame * ntiles + t) * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      lo[e] = a[e];
+      hi[e] = b[e];
+    }
+    cnt = a[3];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      lo[e] = fminf(lo[e], __shfl_xor(lo[e], o, 64));
+      hi[e] = fmaxf(hi[e], __shfl_xor(hi[e], o, 64));
+    }
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  if (lane == 0) {
+    float* b = gbox + id * 8;
+    *reinterpret_cast<f32x4*>(b) = (f32x4){lo[0], lo[1], lo[2], cnt};
+    *reinterpret_cast<f32x4*>(b + 4) = (f32x4){hi[0], hi[1], hi[2], 0.f};
+  }
+}
+
 template <int Q>
 __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const float* __restrict__ xyz, long long P,
                                               const float* __restrict__ coords, int N, int S, int frame0, int frame_step, int T, int K,
                                               int nseg, unsigned long long* __restrict__ keys, int qgroups,
                                               const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch, int seed_fw,
                                               int seed_fh, const float* __restrict__ box, int grid_w, int grid_h,
-                                              int* __restrict__ idx_direct = nullptr) {
+                                              int* __restrict__ idx_direct = nullptr, const float* __restrict__ gbox = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // task id -> (segment, query group, slot); segment fastest so that heavy frames spread over CUs
-  long long task = (long long)blockIdx.x * 4 + wave;
-  const long long ntask = (long long)qgroups * S * nseg;
+  // task id -> (segment, query group, slot); segment fastest so that heavy frames spread over CUs  (32-bit: the launchers bound it)
+  const unsigned task = blockIdx.x * 4u + (unsigned)wave;
+  const unsigned ntask = (unsigned)qgroups * (unsigned)S * (unsigned)nseg;
   if (task >= ntask) return;
-  const int seg = (int)(task % nseg);
-  const int qg = (int)((task / nseg) % qgroups);
-  const int s = (int)(task / ((long long)nseg * qgroups));
+  const unsigned tq = task / (unsigned)nseg;
+  const int seg = (int)(task - tq * (unsigned)nseg);
+  const int s = (int)(tq / (unsigned)qgroups);
+  const int qg = (int)(tq - (unsigned)s * (unsigned)qgroups);
   int frame = frame0 + s * frame_step;
   frame = frame < T - 1 ? frame : T - 1;
   const float* cand = xyz + (long long)frame * P * 4;
-  const long long ntiles = (P + 63) >> 6;
-  const long long tper = (ntiles + nseg - 1) / nseg;
-  const long long t0 = seg * tper;
-  const long long t1 = t0 + tper < ntiles ? t0 + tper : ntiles;
+  const int ntiles = (int)((P + 63) >> 6);
+  const int tper = (ntiles + nseg - 1) / nseg;
+  const int t0 = seg * tper;
+  const int t1 = t0 + tper < ntiles ? t0 + tper : ntiles;
   const float* fbox = box ? box + (long long)frame * ntiles * 8 : nullptr;
 
   unsigned long long* list = lds + (long long)wave * Q * CAP;
@@ -220,10 +253,10 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
     float ub[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) ub[i] = __int_as_float(0x7f800000);
-    for (long long tb = t0; tb < t1; tb += 64) {
-      const long long mt = tb + lane;
+    for (int tb = t0; tb < t1; tb += 64) {
+      const int mt = tb + lane;
       if (mt < t1) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(fbox + mt * 8), hi = *reinterpret_cast<const f32x4*>(fbox + mt * 8 + 4);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(fbox + (long long)mt * 8), hi = *reinterpret_cast<const f32x4*>(fbox + (long long)mt * 8 + 4);
         if (lo[3] >= (float)K) {
 #pragma unroll
           for (int i = 0; i < Q; ++i) {
@@ -247,21 +280,43 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
   const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
   const float qnan = __int_as_float(0x7fc00000);  // lanes past the cloud end carry NaN points: every compare fails
 
-  auto load_tile = [&](long long tile, long long& c) {
+  auto load_tile = [&](int tile, int& c) {
     c = tile_point(tile, lane, grid_w, grid_h);
     f32x4 p = (f32x4){qnan, qnan, qnan, 0.f};
-    if (c < P) p = *reinterpret_cast<const f32x4*>(cand + c * 4);
+    if (c < P) p = *reinterpret_cast<const f32x4*>(cand + (long long)c * 4);
     return p;
   };
 
-  for (long long tb = t0; tb < t1; tb += 64) {
+  // Coarse level (single segment, <= 64 groups of 64 tiles): one group box per lane, same bound arithmetic -- a group box contains
+  // its tiles' boxes, so its bound is <= theirs and a culled group cannot hold a survivor either.
+  unsigned long long gmask = ~0ULL;
+  if (gbox && fbox && nseg == 1 && ntiles > 64 && ntiles <= 64 * 64) {
+    const int ng = (ntiles + 63) >> 6;
+    bool near = false;
+    if (lane < ng) {
+      const float* gb = gbox + ((long long)frame * ng + lane) * 8;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(gb), hi = *reinterpret_cast<const f32x4*>(gb + 4);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const float dx = fmaxf(fmaxf(lo[0] - qx[i], qx[i] - hi[0]), 0.f);
+        const float dy = fmaxf(fmaxf(lo[1] - qy[i], qy[i] - hi[1]), 0.f);
+        const float dz = fmaxf(fmaxf(lo[2] - qz[i], qz[i] - hi[2]), 0.f);
+        const float lb = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+        near = near || !(lb > thr[i]);
+      }
+    }
+    gmask = __ballot(near);
+  }
+
+  for (int tb = t0; tb < t1; tb += 64) {
+    if (!((gmask >> (tb >> 6)) & 1ULL)) continue;  // (t0 = 0 whenever the mask is in use)
     // which of the next 64 tiles can hold a point within thr of any of the Q queries?  One tile per lane.  The bound
     // uses the distance arithmetic of the scan itself on the per-axis gaps to the box, and every rounding step is
     // monotonic, so bound <= d2 of every point in the box in floating point: a culled tile cannot hold a survivor.
-    const long long mt = tb + lane;
+    const int mt = tb + lane;
     bool visit = mt < t1;
     if (fbox && visit) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(fbox + mt * 8), hi = *reinterpret_cast<const f32x4*>(fbox + mt * 8 + 4);
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(fbox + (long long)mt * 8), hi = *reinterpret_cast<const f32x4*>(fbox + (long long)mt * 8 + 4);
       bool near = false;
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
@@ -275,7 +330,7 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
     }
     unsigned long long todo = __ballot(visit);
     if (!todo) continue;
-    long long c, cn = 0;
+    int c, cn = 0;
     f32x4 p = load_tile(tb + __builtin_ctzll(todo), c);
     while (todo) {
       todo &= todo - 1;
@@ -321,7 +376,7 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
     unsigned long long* l = list + i * CAP;
     __builtin_amdgcn_wave_barrier();
     int nc = cnt[i];
-    if (nc > K) {
+    if (nc > 64) {  // (up to 64 entries the rank sort below picks the K smallest directly: cheaper than the radix select)
       unsigned tbits;
       nc = tighten(l, nc, K, lane, lt_mask, &tbits);
     }
@@ -349,10 +404,11 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
                                                        int N, int S, int frame0, int frame_step, int T, int K, int nseg,
                                                        unsigned long long* __restrict__ keys, int qgroups,
                                                        const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch,
-                                                       int seed_fw, int seed_fh, const float* __restrict__ box, int grid_w, int grid_h) {
+                                                       int seed_fw, int seed_fh, const float* __restrict__ box, int grid_w, int grid_h,
+                                                       int* __restrict__ idx_direct, const float* __restrict__ gbox) {
   __shared__ unsigned long long lds[4 * Q * CAP];
   knn_scan_body<Q>(lds, xyz, P, coords, N, S, frame0, frame_step, T, K, nseg, keys, qgroups, seed_idx, seed_k, seed_cw, seed_ch, seed_fw,
-                   seed_fh, box, grid_w, grid_h);
+                   seed_fh, box, grid_w, grid_h, idx_direct, gbox);
 }
 
 // All pyramid levels of one refinement iteration in ONE launch (grid.y = level): after the first iteration every level is
@@ -378,7 +434,7 @@ __global__ __launch_bounds__(256) void knn_search_levels_kernel(KnnLevels a, con
   __shared__ unsigned long long lds[4 * Q * CAP];
   const mvt_knn_level L = a.lv[blockIdx.y];
   knn_scan_body<Q>(lds, L.xyz, L.P, coords, N, S, frame0, frame_step, T, K, 1, nullptr, qgroups, L.seed_idx, seed_k, 0, 0, 0, 0, L.tile_box,
-                   L.grid_w, L.grid_h, L.idx_out);
+                   L.grid_w, L.grid_h, L.idx_out, L.group_box);
 }
 
 // Merge the nseg per-segment lists of one (track, slot) into its K nearest neighbour indices.  Every lane holds
@@ -586,12 +642,40 @@ extern "C" int mvt_tile_aabb(const float* xyz, long long P, int T, int grid_w, i
   return mvt_launch_status();
 }
 
+extern "C" int mvt_tile_group_aabb(const float* box, long long P, int T, float* group_box, void* stream) {
+  MVT_REQUIRE(box && group_box && P > 0 && T > 0 && P < (1LL << 31));
+  const long long ntiles = (P + 63) / 64, ngroups = (ntiles + 63) / 64, total = ngroups * T;
+  hipLaunchKernelGGL(tile_group_aabb_kernel, dim3((unsigned)mvt_cdiv(total, 4)), dim3(256), 0, mvt_stream(stream), box, ntiles, ngroups, total,
+                     group_box);
+  return mvt_launch_status();
+}
+
+static int knn_scan_launch(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step, int T, int K, int nseg,
+                           unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw, int seed_ch, int seed_fw, int seed_fh,
+                           const float* tile_box, int grid_w, int grid_h, int* idx_direct, const float* group_box, void* stream);
+
 extern "C" int mvt_knn_scan(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step, int T,
                             int K, int nseg, unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw, int seed_ch,
                             int seed_fw, int seed_fh, const float* tile_box, int grid_w, int grid_h, void* stream) {
+  MVT_REQUIRE(keys);
+  return knn_scan_launch(xyz, P, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_idx, seed_k, seed_cw, seed_ch, seed_fw, seed_fh,
+                         tile_box, grid_w, grid_h, nullptr, nullptr, stream);
+}
+
+extern "C" int mvt_knn_search(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step, int T, int K,
+                              const int* seed_idx, int seed_k, int seed_cw, int seed_ch, int seed_fw, int seed_fh, const float* tile_box,
+                              const float* group_box, int grid_w, int grid_h, int* idx_out, void* stream) {
+  MVT_REQUIRE(idx_out && tile_box);
+  return knn_scan_launch(xyz, P, coords, N, S, frame0, frame_step, T, K, 1, nullptr, seed_idx, seed_k, seed_cw, seed_ch, seed_fw, seed_fh,
+                         tile_box, grid_w, grid_h, idx_out, group_box, stream);
+}
+
+static int knn_scan_launch(const float* xyz, long long P, const float* coords, int N, int S, int frame0, int frame_step, int T, int K, int nseg,
+                           unsigned long long* keys, const int* seed_idx, int seed_k, int seed_cw, int seed_ch, int seed_fw, int seed_fh,
+                           const float* tile_box, int grid_w, int grid_h, int* idx_direct, const float* group_box, void* stream) {
   MVT_REQUIRE(!seed_idx || (seed_k >= K && seed_k <= 64 && seed_cw >= 0));
   MVT_REQUIRE(!seed_idx || seed_cw == 0 || (seed_ch > 0 && seed_fw >= 2 * seed_cw && seed_fh >= 2 * seed_ch));
-  MVT_REQUIRE(xyz && coords && keys && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0);
+  MVT_REQUIRE(xyz && coords && (keys || idx_direct) && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0);
   MVT_REQUIRE(K >= 1 && K <= 16 && nseg >= 1 && nseg * K <= 64 && P < (1LL << 31) && P >= K);
   MVT_REQUIRE((grid_w == 0 && grid_h == 0) || (grid_w > 0 && grid_h > 0 && grid_w % 8 == 0 && grid_h % 8 == 0 && P % ((long long)grid_w * grid_h) == 0));
   const long long ntiles = (P + 63) / 64, tper = (ntiles + nseg - 1) / nseg;
@@ -602,10 +686,11 @@ extern "C" int mvt_knn_scan(const float* xyz, long long P, const float* coords, 
   const int Q = q_env ? q_env : (tile_box ? 2 : 8);
   const int qgroups = (N + Q - 1) / Q;
   const long long ntask = (long long)qgroups * S * nseg;
+  MVT_REQUIRE(ntask < (1LL << 31));
 #define LAUNCH(QQ)                                                                                                                   \
   hipLaunchKernelGGL((knn_scan_kernel<QQ>), dim3((unsigned)mvt_cdiv(ntask, 4)), dim3(256), 0, mvt_stream(stream), xyz, P, coords, N, S, \
                      frame0, frame_step, T, K, nseg, keys, qgroups, seed_idx, seed_k, seed_cw, seed_ch, seed_fw, seed_fh, tile_box,    \
-                     grid_w, grid_h)
+                     grid_w, grid_h, idx_direct, group_box)
   switch (Q) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -643,6 +728,7 @@ extern "C" int mvt_knn_scan_levels(int levels, const mvt_knn_level* lv, const fl
   static const int q_env = getenv("MVT_KNN_Q") ? atoi(getenv("MVT_KNN_Q")) : 0;
   const int Q = q_env ? q_env : (boxes ? 2 : 8);
   const int qgroups = (N + Q - 1) / Q;
+  MVT_REQUIRE((long long)qgroups * S * max_nseg < (1LL << 31));
   const dim3 grid((unsigned)mvt_cdiv((long long)qgroups * S * max_nseg, 4), (unsigned)levels);
 #define LAUNCH(QQ)                                                                                                              \
   hipLaunchKernelGGL((knn_scan_levels_kernel<QQ>), grid, dim3(256), 0, mvt_stream(stream), a, coords, N, S, frame0, frame_step, T, K, \
@@ -687,6 +773,7 @@ extern "C" int mvt_knn_search_levels(int levels, const mvt_knn_level* lv, const 
   static const int q_env = getenv("MVT_KNN_Q") ? atoi(getenv("MVT_KNN_Q")) : 0;
   const int Q = q_env ? q_env : 2;
   const int qgroups = (N + Q - 1) / Q;
+  MVT_REQUIRE((long long)qgroups * S < (1LL << 31));
   const dim3 grid((unsigned)mvt_cdiv((long long)qgroups * S, 4), (unsigned)levels);
 #define LAUNCH(QQ)                                                                                                                \
   hipLaunchKernelGGL((knn_search_levels_kernel<QQ>), grid, dim3(256), 0, mvt_stream(stream), a, coords, N, S, frame0, frame_step, T, K, \

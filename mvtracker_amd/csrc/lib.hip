@@ -1,7 +1,7 @@
 // Library introspection entry points.
 #include "common.h"
 
-extern "C" int mvt_abi_version(void) { return 2; }
+extern "C" int mvt_abi_version(void) { return 3; }
 extern "C" const char* mvt_build_arch(void) { return "gfx950"; }
 
 // A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): the tracker encodes later frames on

@@ -62,6 +62,8 @@ SIGNATURES = {
     "mvt_adapter_best_view": [P, P, P, P, I, I, I, I, I, P, P, P],
     "mvt_knn_scan_levels": [I, P, P, I, I, I, I, I, I, I, P],
     "mvt_knn_search_levels": [I, P, P, I, I, I, I, I, I, I, P],
+    "mvt_knn_search": [P, LL, P, I, I, I, I, I, I, P, I, I, I, I, I, P, P, I, I, P, P],
+    "mvt_tile_group_aabb": [P, LL, I, P, P],
     "mvt_knn_merge_levels": [I, P, I, I, I, P],
     "mvt_corr_gather_dot": [I, P, P, I, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
     "mvt_knn1_gather": [P, I, LL, I, P, I, I, I, P, P, P],
@@ -368,7 +370,7 @@ def knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, nseg, keys, seed_i
 class KnnLevel(C.Structure):
     """mvt_knn_level of include/mvtracker_hip.h."""
     _fields_ = [("xyz", C.c_void_p), ("P", C.c_longlong), ("keys", C.c_void_p), ("seed_idx", C.c_void_p), ("tile_box", C.c_void_p),
-                ("nseg", C.c_int), ("grid_w", C.c_int), ("grid_h", C.c_int), ("idx_out", C.c_void_p)]
+                ("nseg", C.c_int), ("grid_w", C.c_int), ("grid_h", C.c_int), ("idx_out", C.c_void_p), ("group_box", C.c_void_p)]
 
 
 def _knn_levels(levels):
@@ -376,7 +378,7 @@ def _knn_levels(levels):
     for i, lv in enumerate(levels):
         g = lv.get("grid", (0, 0))
         arr[i] = KnnLevel(_ptr(lv["xyz"]), lv["P"], _ptr(lv["keys"]), _ptr(lv.get("seed_idx")), _ptr(lv.get("box")), lv["nseg"], g[0], g[1],
-                          _ptr(lv.get("idx_out")))
+                          _ptr(lv.get("idx_out")), _ptr(lv.get("gbox")))
     return arr
 
 
@@ -386,8 +388,20 @@ def knn_scan_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k=0):
     _call("mvt_knn_scan_levels", len(levels), C.cast(arr, C.c_void_p), _ptr(coords), N, S, frame0, frame_step, T, K, seed_k, _stream())
 
 
+def tile_group_aabb(box, Pn, T, group_box):
+    """group_box [T][ceil(ntiles/64)][8]: union boxes of 64 consecutive tiles (coarse culling level of the searches)."""
+    _call("mvt_tile_group_aabb", _ptr(box), Pn, T, _ptr(group_box), _stream())
+
+
+def knn_search(xyz, Pn, coords, N, S, frame0, frame_step, T, K, idx_out, box, grid=(0, 0), gbox=None, seed_idx=None, seed_k=0,
+               seed_dims=(0, 0, 0, 0)):
+    """``knn_scan`` (one segment) + ``knn_merge`` in one launch: neighbour indices straight to idx_out (N,S,K) int32."""
+    _call("mvt_knn_search", _ptr(xyz), Pn, _ptr(coords), N, S, frame0, frame_step, T, K, _ptr(seed_idx), seed_k, *seed_dims, _ptr(box),
+          _ptr(gbox), grid[0], grid[1], _ptr(idx_out), _stream())
+
+
 def knn_search_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k):
-    """Seeded scan + merge in one launch: levels of dicts(xyz, P, seed_idx, box, grid, idx_out); idx_out may alias seed_idx."""
+    """Seeded scan + merge in one launch: levels of dicts(xyz, P, seed_idx, box, grid, idx_out[, gbox]); idx_out may alias seed_idx."""
     arr = _knn_levels([dict(lv, keys=None, nseg=1) for lv in levels])
     _call("mvt_knn_search_levels", len(levels), C.cast(arr, C.c_void_p), _ptr(coords), N, S, frame0, frame_step, T, K, seed_k, _stream())
 

@@ -560,15 +560,22 @@ class MVTracker(nn.Module):
             xyz.append(o)
         P = [V * (hs >> lvl) * (ws >> lvl) for lvl in range(self.corr_n_levels)]
         # bounding boxes of the 64-point scan tiles (8x8 pixel patches where the grid allows it): the kNN scan culls with them
-        box, tgrid = [], []
+        # ... and the union boxes of 64 consecutive tiles, the coarse level the single-wave searches test first
+        box, tgrid, gbox = [], [], []
         for lvl in range(self.corr_n_levels):
             h, w = hs >> lvl, ws >> lvl
             g = (w, h) if (w % 8 == 0 and h % 8 == 0) else (0, 0)
-            b = torch.empty(T, (P[lvl] + 63) // 64, 8, device=dev)
+            nt = (P[lvl] + 63) // 64
+            b = torch.empty(T, nt, 8, device=dev)
             hip.tile_aabb(xyz[lvl], P[lvl], T, b, g)
+            gb = None
+            if nt > 64:
+                gb = torch.empty(T, (nt + 63) // 64, 8, device=dev)
+                hip.tile_group_aabb(b, P[lvl], T, gb)
             box.append(b)
             tgrid.append(g)
-        return {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds, "box": box, "tile_grid": tgrid}
+            gbox.append(gb)
+        return {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds, "box": box, "tile_grid": tgrid, "gbox": gbox}
 
     def _nseg(self, P: int, K: int) -> int:
         """Segments (runs of 64-point tiles) scanned by different waves; none may be empty."""
@@ -823,7 +830,7 @@ class MVTracker(nn.Module):
         grid = [tuple(store["xyz"][lvl].shape[2:4]) for lvl in range(L)]  # per-view (h, w) of each level
         preds = []
         levels = [dict(xyz=store["xyz"][lvl], P=store["P"][lvl], keys=keys[lvl], nseg=nsegs[lvl], seed_idx=idx[lvl], box=store["box"][lvl],
-                       grid=store["tile_grid"][lvl], idx_out=idx[lvl]) for lvl in range(L)]
+                       grid=store["tile_grid"][lvl], idx_out=idx[lvl], gbox=store["gbox"][lvl]) for lvl in range(L)]
         for it in range(iters):
             if it > 0:
                 # every level is seeded by its own previous neighbours: the four scans are independent -> one launch
@@ -856,6 +863,10 @@ class MVTracker(nn.Module):
                         if lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
                             seed = dict(seed_idx=idx[lvl + 1][n0:], seed_k=K,
                                         seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
+                        if self.knn_one_launch:
+                            hip.knn_search(store["xyz"][lvl], P, coords[n0:], m, S, frame0, 1, T, K, idx[lvl][n0:], store["box"][lvl],
+                                           grid=store["tile_grid"][lvl], gbox=store["gbox"][lvl], **seed)
+                            continue
                         kl = keys[lvl][n0 * S * nsegs[lvl] * K:]
                         hip.knn_scan(store["xyz"][lvl], P, coords[n0:], m, S, frame0, 1, T, K, nsegs[lvl], kl, box=store["box"][lvl],
                                      grid=store["tile_grid"][lvl], **seed)

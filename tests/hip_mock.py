@@ -308,6 +308,23 @@ def knn_scan_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k=0):
                  seed_k=seed_k, box=lv.get("box"), grid=lv.get("grid", (0, 0)))
 
 
+def tile_group_aabb(box, Pn, T, group_box):
+    nt = (Pn + 63) // 64
+    for g in range((nt + 63) // 64):
+        b = box[:, 64 * g:64 * g + 64]
+        group_box[:, g, 0:3] = b[..., 0:3].amin(1)
+        group_box[:, g, 3] = b[..., 3].sum(1)
+        group_box[:, g, 4:7] = b[..., 4:7].amax(1)
+        group_box[:, g, 7] = 0
+
+
+def knn_search(xyz, Pn, coords, N, S, frame0, frame_step, T, K, idx_out, box, grid=(0, 0), gbox=None, seed_idx=None, seed_k=0,
+               seed_dims=(0, 0, 0, 0)):
+    keys = torch.empty(N * S * K, dtype=torch.int64, device=coords.device)
+    knn_scan(xyz, Pn, coords, N, S, frame0, frame_step, T, K, 1, keys, seed_idx=seed_idx, seed_k=seed_k, seed_dims=seed_dims, box=box, grid=grid)
+    knn_merge(keys, N, S, K, 1, Pn, idx_out)
+
+
 def knn_search_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k):
     for lv in levels:
         keys = torch.empty(N * S * K, dtype=torch.int64, device=coords.device)
@@ -458,7 +475,7 @@ def install(monkeypatch):
     from mvtracker_amd import hip
     me = sys.modules[__name__]
     for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 ln_proj_bf16 mlp_fused_bf16 rgb_to_nhwc4 rgb_images_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac concat_resize_bilinear_ac invert_cameras "
-                 "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_search_levels knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
+                 "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_search_levels knn_search tile_group_aabb knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr window_prepare window_store require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))
     monkeypatch.setattr(hip, "COMPOSITE", False)  # the per-kernel sequencing is what these tests exercise

@@ -641,6 +641,21 @@ def test_knn_tile_culling_is_exact(hip, patch, nseg):
     _, ref2 = O.knn_exact(K, torch.where(torch.isnan(xyz), torch.full_like(xyz, 1e18), xyz), q2)
     idx2 = run(seed_idx=idx, seed_k=K)
     assert torch.equal(idx2.permute(1, 0, 2).cpu().long(), ref2)
+    # single-wave search (scan + merge in one launch), with and without the coarse group boxes
+    gbox = torch.empty(B, ((P + 63) // 64 + 63) // 64, 8, device=DEV)
+    hip.tile_group_aabb(box, P, B, gbox)
+    torch.cuda.synchronize()
+    nt = (P + 63) // 64
+    bc = box.cpu()
+    for gi in range(gbox.shape[1]):
+        assert torch.equal(gbox[:, gi, 0:3].cpu(), bc[:, 64 * gi:64 * gi + 64, 0:3].amin(1))
+        assert torch.equal(gbox[:, gi, 4:7].cpu(), bc[:, 64 * gi:64 * gi + 64, 4:7].amax(1))
+    for gb in (None, gbox):
+        for kw, want in ((dict(), ref2), (dict(seed_idx=idx, seed_k=K), ref2)):
+            out = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
+            hip.knn_search(x4g, P, cd, M, B, 0, 1, B, K, out, box, grid=grid, gbox=gb, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(out.permute(1, 0, 2).cpu().long(), want)
 
 
 def test_knn_levels_one_launch(hip):
@@ -699,7 +714,13 @@ def test_knn_levels_one_launch(hip):
         assert torch.equal(a, b)
     # mvt_knn_search_levels: scan + merge in one launch, one wave per (track, slot), IN PLACE (idx_out aliases seed_idx)
     inpl = [r.clone() for r in ref]
-    lv = [dict(xyz=clouds[l], P=V * h * w, seed_idx=inpl[l], box=boxes[l], grid=(w, h), idx_out=inpl[l]) for l, (h, w) in enumerate(grids)]
+    gbs = []
+    for l, (h, w) in enumerate(grids):
+        gb = torch.empty(B, ((V * h * w + 63) // 64 + 63) // 64, 8, device=DEV)
+        hip.tile_group_aabb(boxes[l], V * h * w, B, gb)
+        gbs.append(gb)
+    lv = [dict(xyz=clouds[l], P=V * h * w, seed_idx=inpl[l], box=boxes[l], grid=(w, h), idx_out=inpl[l], gbox=gbs[l])
+          for l, (h, w) in enumerate(grids)]
     hip.knn_search_levels(lv, q, M, B, 0, 1, B, K, seed_k=K)
     torch.cuda.synchronize()
     for a, b in zip(ref2, inpl):
