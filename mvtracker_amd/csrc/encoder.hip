@@ -1,6 +1,8 @@
 // HBM-bound encoder-side kernels: input repack, nearest / align-corners bilinear resize,
 // InstanceNorm statistics and the fused normalise + ReLU (+ residual) pass.  All tensors are
 // channels-last; every thread moves 16 bytes.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -170,6 +172,87 @@ __global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* 
       for (int e = 0; e < 4; ++e) o[e] = fmaxf(k[e] + o[e], 0.0f);
     }
     store_act4(y, i * 4, o, bf);
+  }
+}
+
+// bf16 tensors, C % 8 == 0: a block owns a run of pixels of ONE image (grid.y = image), a thread owns one channel octet --
+// its statistics sit in registers, every access is 16 bytes, and there is no integer division in the loop (the generic kernel
+// above spends a 64-bit division per element quad and re-reads the statistics for every quad).  UN pixels per thread are in
+// flight together.
+template <bool SKIP, bool SKST>
+__global__ __launch_bounds__(256) void instnorm_apply_bf16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ st,
+                                                                  const unsigned short* __restrict__ skip, const float* __restrict__ skst,
+                                                                  unsigned short* __restrict__ y, int HW, int C, int ppb, int skip_relu) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int UN = 4;
+  const int c8n = C >> 3;                       // octets per pixel
+  const int lanes = (256 / c8n) * c8n;          // active threads (whole pixels)
+  const int t = threadIdx.x;
+  if (t >= lanes) return;
+  const int oc = t % c8n, p0 = t / c8n, pstep = 256 / c8n;
+  const long long img = blockIdx.y;
+  float m[8], rs[8], km[8], kr[8];
+  {
+    const float* s = st + (img * C + oc * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      m[e] = s[2 * e];
+      rs[e] = s[2 * e + 1];
+    }
+    if (SKST) {
+      const float* k = skst + (img * C + oc * 8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        km[e] = k[2 * e];
+        kr[e] = k[2 * e + 1];
+      }
+    }
+  }
+  const int pb = blockIdx.x * ppb, pe = min(pb + ppb, HW);
+  const long long base = img * (long long)HW * C + oc * 8;
+  auto unpack = [](const u32x4& w, float (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = __uint_as_float(w[e] << 16);
+      f[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u);
+    }
+  };
+  for (int p = pb + p0; p < pe; p += pstep * UN) {
+    u32x4 xv[UN], kv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pp = p + u * pstep;
+      if (pp < pe) {
+        xv[u] = *reinterpret_cast<const u32x4*>(x + base + (long long)pp * C);
+        if (SKIP) kv[u] = *reinterpret_cast<const u32x4*>(skip + base + (long long)pp * C);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pp = p + u * pstep;
+      if (pp >= pe) break;
+      float f[8], k[8];
+      unpack(xv[u], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fmaxf((f[e] - m[e]) * rs[e], 0.0f);
+      if (SKIP) {
+        unpack(kv[u], k);
+        if (SKST) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) k[e] = (k[e] - km[e]) * kr[e];
+          if (skip_relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) k[e] = fmaxf(k[e], 0.0f);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fmaxf(k[e] + f[e], 0.0f);
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (unsigned)mvt_bf16_bits(f[2 * e]) | ((unsigned)mvt_bf16_bits(f[2 * e + 1]) << 16);
+      *reinterpret_cast<u32x4*>(y + base + (long long)pp * C) = o;
+    }
   }
 }
 
@@ -354,6 +437,27 @@ extern "C" int mvt_instnorm_apply(const void* x, const float* mean_rstd, const v
   MVT_REQUIRE(io_flags == 0 || io_flags == both);  // x, skip and y share one element type
   MVT_REQUIRE(!skip_relu || skip_stats);
   MVT_REQUIRE(skip || !skip_stats);
+  static const bool generic = getenv("MVT_APPLY_GENERIC") != nullptr;  // tuning / A-B switch
+  if (io_flags && C % 8 == 0 && C <= 2048 && HW < (1LL << 31) && !generic && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
+      ((uintptr_t)skip % 16 == 0)) {
+    // pixels per block: ~8 waves of blocks per CU-slot keeps the tail short; at least one full sweep of the block's threads
+    const int pstep = 256 / (C / 8);
+    long long ppb = (HW * n + 8191) / 8192;
+    ppb = (ppb + pstep * 4 - 1) / (pstep * 4) * (pstep * 4);
+    const dim3 grid((unsigned)mvt_cdiv(HW, ppb), (unsigned)n);
+    const unsigned short *xs = (const unsigned short*)x, *ks = (const unsigned short*)skip;
+    unsigned short* ys = (unsigned short*)y;
+    if (!skip)
+      hipLaunchKernelGGL((instnorm_apply_bf16_kernel<false, false>), grid, dim3(256), 0, mvt_stream(stream), xs, mean_rstd, ks, skip_stats, ys,
+                         (int)HW, C, (int)ppb, skip_relu);
+    else if (!skip_stats)
+      hipLaunchKernelGGL((instnorm_apply_bf16_kernel<true, false>), grid, dim3(256), 0, mvt_stream(stream), xs, mean_rstd, ks, skip_stats, ys,
+                         (int)HW, C, (int)ppb, skip_relu);
+    else
+      hipLaunchKernelGGL((instnorm_apply_bf16_kernel<true, true>), grid, dim3(256), 0, mvt_stream(stream), xs, mean_rstd, ks, skip_stats, ys,
+                         (int)HW, C, (int)ppb, skip_relu);
+    return mvt_launch_status();
+  }
   long long total4 = (long long)n * HW * (C / 4);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, mvt_stream(stream), (const float*)x, mean_rstd,
                      (const float*)skip, skip_stats, (float*)y, HW, C, total4, io_flags ? 1 : 0, skip_relu);
