@@ -9,17 +9,22 @@ namespace {
 __global__ void pos_embed_kernel(const float* __restrict__ coords, int N, int S, int D, int dim3, const double* __restrict__ omega_tab,
                                  float* __restrict__ pos) {
   const int A = dim3 / 3, half = A / 2;
-  const long long total = (long long)N * D;
+  // one thread per (track, axis, frequency): the sine and the cosine of an argument share one fp64 argument reduction (sincos)
+  const int per = 3 * half;
+  const long long total = (long long)N * per;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int d = (int)(i % D);
-    const long long n = i / D;
-    const int a = d / A, j = d - a * A;
-    const int jj = j < half ? j : j - half;
+    const int q = (int)(i % per);
+    const long long n = i / per;
+    const int a = q / half, jj = q - a * half;
     // omega_j = 10000^(-j / (A/2)): from the caller's table (the reference's numpy values, embeddings.py:95-97; the fp64 pow
     // per element was most of this kernel's time) or computed here
     const double omega = omega_tab ? omega_tab[jj] : 1.0 / pow(10000.0, (double)jj / ((double)A / 2.0));
     const double arg = (double)coords[(n * S) * 3 + a] * omega;
-    pos[i] = (float)(j < half ? sin(arg) : cos(arg));
+    double sn, cs;
+    sincos(arg, &sn, &cs);
+    const int ds = a * A + jj, dc = ds + half;
+    if (ds < D) pos[n * D + ds] = (float)sn;
+    if (dc < D) pos[n * D + dc] = (float)cs;
   }
 }
 
@@ -215,7 +220,7 @@ inline unsigned grid_for(long long total) {
 
 extern "C" int mvt_pos_embed(const float* coords, int N, int S, int D, int dim_padded, const double* omega, float* pos, void* stream) {
   MVT_REQUIRE(coords && pos && N > 0 && S > 0 && D > 0 && dim_padded % 6 == 0 && D <= dim_padded);
-  hipLaunchKernelGGL(pos_embed_kernel, dim3(grid_for((long long)N * D)), dim3(256), 0, mvt_stream(stream), coords, N, S, D, dim_padded,
+  hipLaunchKernelGGL(pos_embed_kernel, dim3(grid_for((long long)N * (dim_padded / 2))), dim3(256), 0, mvt_stream(stream), coords, N, S, D, dim_padded,
                      omega, pos);
   return mvt_launch_status();
 }
