@@ -157,8 +157,9 @@ int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 whe
                          const unsigned short* wo, int ldwo,
                          const float* bo, const unsigned short* w1, int ldw1, const float* b1, const unsigned short* w2,
                          int ldw2, const float* b2, int H, const mvt_block_next* next, int n_next, long long M, int C,
-                         float* workspace /* NULL, or (H/256 + 1) * M * C floats: lets small M (<= 2048 rows) run as two
-                                             launches cut over 4x more workgroups (deterministic partial sums) */,
+                         float* workspace /* NULL, or (H/256 + 1) * M * C floats: lets small M (<= 2048 rows, M % 32 == 0) run
+                                             as two launches cut over 4x more workgroups (deterministic partial sums); scratch
+                                             in the kernels' own tile order, no state between calls */,
                          void* stream);
 
 /* mvt_block_fused_bf16 with the attention that precedes the block computed INSIDE the kernel (no attention launch, no
@@ -167,7 +168,8 @@ int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 whe
  *                  q, k, v [M][ld] bf16 indexed by the block's rows.
  *   MVT_ATTN_FRAME (CrossAttnBlock / AttnBlock over space, blocks.py:477-483): the tokens of frame t attend over the
  *                  n_keys <= 64 context tokens of frame t; q [M][ldq] indexed by the block's rows, k / v [n_keys * S][ldkv]
- *                  with context token j of frame t at row j * S + t.  M < 4096: two-launch split path, workspace required. */
+ *                  with context token j of frame t at row j * S + t.  M < 4096: two-launch split path, workspace required,
+ *                  (M / S) % 32 == 0. */
 #define MVT_ATTN_TIME 1
 #define MVT_ATTN_FRAME 2
 /*   MVT_ATTN_PARTIALS: the attention was computed key-split by mvt_attention_bf16(MVT_ATTN_PARTIALS_ONLY) (64 queries per

@@ -232,15 +232,17 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
   }
   if (!chunk_ok) return;
   if (ws) {
-    float* rr = ws + ((blockIdx.y * nchunk + chunk_id) * 64 + lane) * 68;
+    {
+      const long long rec = blockIdx.y * nchunk + chunk_id;
+      *reinterpret_cast<f32x4*>(ws + mvt_part_off(rec, 0, lane)) = (f32x4){m[0], m[1], l[0], l[1]};
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      rr[mb] = m[mb];
-      rr[2 + mb] = l[mb];
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) rr[4 + (mb * 2 + db) * 16 + e] = oacc[mb][db][e];
+          for (int gq = 0; gq < 4; ++gq)
+            *reinterpret_cast<f32x4*>(ws + mvt_part_off(rec, 1 + (mb * 2 + db) * 4 + gq, lane)) =
+                (f32x4){oacc[mb][db][4 * gq], oacc[mb][db][4 * gq + 1], oacc[mb][db][4 * gq + 2], oacc[mb][db][4 * gq + 3]};
     }
     if (!tickets) return;  // attention_merge_kernel finishes
     // Merge without a second launch: the workgroup that publishes its partial LAST (ticket counter per chunk) combines the
@@ -253,32 +255,46 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
     if (tk + 1 != gridDim.y) return;
     __threadfence();
     if (lane == 0) tickets[chunk_id] = 0u;  // left zero for the next launch
+    auto ntl = [&](long long rec, int quad) {
+      const float* q = ws + mvt_part_off(rec, quad, lane);
+      return (f32x4){__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2),
+                     __builtin_nontemporal_load(q + 3)};
+    };
     {
-      const float* r0 = ws + (chunk_id * 64 + lane) * 68;
+      const f32x4 q0 = ntl(chunk_id, 0);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        m[mb] = __builtin_nontemporal_load(r0 + mb);
-        l[mb] = __builtin_nontemporal_load(r0 + 2 + mb);
+        m[mb] = q0[mb];
+        l[mb] = q0[2 + mb];
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = __builtin_nontemporal_load(r0 + 4 + (mb * 2 + db) * 16 + e);
+          for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 t = ntl(chunk_id, 1 + (mb * 2 + db) * 4 + gq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oacc[mb][db][4 * gq + e] = t[e];
+          }
       }
     }
 #pragma unroll 1
     for (int w = 1; w < (int)gridDim.y; ++w) {
-      const float* rw = ws + ((w * nchunk + chunk_id) * 64 + lane) * 68;
+      const long long rec = w * nchunk + chunk_id;
+      const f32x4 q0 = ntl(rec, 0);
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        const float mw = __builtin_nontemporal_load(rw + mb);
+        const float mw = q0[mb];
         const float mn = fmaxf(m[mb], mw);
         const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
         const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-        l[mb] = fmaf(l[mb], ca, __builtin_nontemporal_load(rw + 2 + mb) * cb);
+        l[mb] = fmaf(l[mb], ca, q0[2 + mb] * cb);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) oacc[mb][db][e] = fmaf(oacc[mb][db][e], ca, __builtin_nontemporal_load(rw + 4 + (mb * 2 + db) * 16 + e) * cb);
+          for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 t = ntl(rec, 1 + (mb * 2 + db) * 4 + gq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oacc[mb][db][4 * gq + e] = fmaf(oacc[mb][db][4 * gq + e], ca, t[e] * cb);
+          }
         m[mb] = mn;
       }
     }
@@ -320,32 +336,42 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* __res
   const long long g = cid / ((long long)chunks * heads);
   float m[2], l[2];
   f32x16 oacc[2][2];
+  auto ld = [&](long long rec, int quad) { return *reinterpret_cast<const f32x4*>(ws + mvt_part_off(rec, quad, lane)); };
   {
-    const float* rr = ws + (cid * 64 + lane) * 68;
+    const f32x4 q0 = ld(cid, 0);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      m[mb] = rr[mb];
-      l[mb] = rr[2 + mb];
+      m[mb] = q0[mb];
+      l[mb] = q0[2 + mb];
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[mb][db][e] = rr[4 + (mb * 2 + db) * 16 + e];
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 t = ld(cid, 1 + (mb * 2 + db) * 4 + gq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) oacc[mb][db][4 * gq + e] = t[e];
+        }
     }
   }
 #pragma unroll 1
   for (int w = 1; w < nsplit; ++w) {
-    const float* rr = ws + ((w * nchunk + cid) * 64 + lane) * 68;
+    const long long rec = w * nchunk + cid;
+    const f32x4 q0 = ld(rec, 0);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      const float mw = rr[mb];
+      const float mw = q0[mb];
       const float mn = fmaxf(m[mb], mw);
       const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
       const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-      l[mb] = fmaf(l[mb], ca, rr[2 + mb] * cb);  // (explicit: every merge variant rounds identically)
+      l[mb] = fmaf(l[mb], ca, q0[2 + mb] * cb);  // (explicit: every merge variant rounds identically)
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[mb][db][e] = fmaf(oacc[mb][db][e], ca, rr[4 + (mb * 2 + db) * 16 + e] * cb);
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 t = ld(rec, 1 + (mb * 2 + db) * 4 + gq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) oacc[mb][db][4 * gq + e] = fmaf(oacc[mb][db][4 * gq + e], ca, t[e] * cb);
+        }
       m[mb] = mn;
     }
   }

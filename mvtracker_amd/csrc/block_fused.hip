@@ -48,13 +48,20 @@ constexpr int FS = 512;   // elements per (32-row block, k-step) weight fragment
 // slot per (workgroup, wave, stamp), in a buffer of its own.  No stamp executes in the shipped library.
 #ifdef MVT_STAMPS
 __device__ unsigned long long mvt_stamp_buf[2 * 8 * 64];
+// -DMVT_STAMP_SEL="(NMB == 1 && MODE == 2 && ATT == 0)" restricts the stamps to one instantiation (a whole updater call runs many)
+#ifndef MVT_STAMP_SEL
+#define MVT_STAMP_SEL true
+#endif
+#ifndef MVT_STAMP_WG1
+#define MVT_STAMP_WG1 100
+#endif
 #define STAMP(i)                                                                                                  \
   do {                                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     unsigned long long t_;                                                                                        \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
-    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && blockIdx.y == 0 && blockIdx.z == 0)                \
+    if (lane == 0 && MVT_STAMP_SEL && (blockIdx.x == 0 || blockIdx.x == MVT_STAMP_WG1) && blockIdx.y == 0 && blockIdx.z == 0) \
       mvt_stamp_buf[((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + (i)] = t_;                                           \
   } while (0)
 #else
@@ -552,8 +559,10 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
-  static_assert(ATT == 0 || MODE != 2, "pass 2 of the split path has no attention");
-  constexpr bool FM = ATT == 2 || ATT == 3;                    // frame-major tile: tokens blockIdx.x*BM.. of frame blockIdx.z
+  static_assert(ATT == 0 || ATT == 5 || MODE != 2, "pass 2 of the split path has no attention");
+  static_assert(ATT != 5 || MODE == 2, "ATT 5 = pass 2 on the frame-major tiles of an ATT 2 / ATT 3 pass 1");
+  static_assert((MODE != 1 && MODE != 2) || NMB == 1, "the split path runs on 32-row tiles");
+  constexpr bool FM = ATT == 2 || ATT == 3 || ATT == 5;        // frame-major tile: tokens blockIdx.x*BM.. of frame blockIdx.z
   const int bmv = ATT == 1 ? p.bmv : BM;                      // rows of the tile that hold tokens
   const long long m0 = FM ? 0 : (long long)blockIdx.x * bmv;
   const long long ntok = FM ? p.M / p.S : 0;                   // tokens per frame
@@ -573,7 +582,13 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
                                                     // read-only x in whole 64-row tiles (mvt_ln_proj_bf16 at large M)
   if (HAS_MLP)
     for (int i = t; i < p.H; i += NT) b1s[i] = p.b1[i];
-  const long long MC = p.M * (long long)C;
+  // Split-path workspace: [chunk 0 = x after the projection, 1.. = MLP partials][tile][wave][g][lane][4 floats] -- the accumulator
+  // layout itself, so that pass 1's stores and pass 2's loads are contiguous 1-KiB pieces per wave instruction (as [M][C] rows
+  // every access of a wave touched 32 different rows and pass 2 spent half its time on these loads).  Both passes use the same
+  // tiling (grid.x, grid.z), hence the same (tile, wave, g, lane) <-> element map.
+  const long long ws_tile = FM ? (long long)blockIdx.z * gridDim.x + blockIdx.x : (long long)blockIdx.x;
+  const long long ws_ntile = FM ? (long long)gridDim.z * gridDim.x : (long long)gridDim.x;
+  auto ws_off = [&](int chunk, int g) -> long long { return ((((long long)chunk * ws_ntile + ws_tile) * 8 + wave) * 4 + g) * 256 + lane * 4; };
   // a projection runs in this workgroup when its row range meets the workgroup's rows (workgroup-uniform)
   auto active = [&](int q) { return q < p.n_next && rlo < p.next[q].row_hi && rhi > p.next[q].row_lo; };
   bf16x8 wq[PFQ];  // the weight-fragment queue, chained through the MLP and the follow-up projections
@@ -682,32 +697,46 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       const int mb = (int)blockIdx.x;
       const long long nchunk = (long long)p.S * 6;
       const long long cid = (long long)blockIdx.z * 6 + wave;
-      const float* r0 = p.parts + (cid * 64 + lane) * 68;
-      float mm = r0[mb], ll = r0[2 + mb];
+      // the records of ALL splits are requested before the first is combined (they were written by other CUs: as a load-combine
+      // loop over the splits every iteration paid its own trip to the memory side); MVT_ATTN_NSPLIT splits at most
+      constexpr int MAXS = MVT_ATTN_NSPLIT;
+      float ms[MAXS], ls[MAXS];
+      f32x4 os[MAXS][2][4];
+#pragma unroll
+      for (int w = 0; w < MAXS; ++w) {
+        const long long rec = (w < p.nsplit ? w : 0) * nchunk + cid;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(p.parts + mvt_part_off(rec, 0, lane));
+        ms[w] = q0[mb];
+        ls[w] = q0[2 + mb];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            os[w][db][g] = *reinterpret_cast<const f32x4*>(p.parts + mvt_part_off(rec, 1 + (mb * 2 + db) * 4 + g, lane));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from sinking the loads back to their uses)
+      float mm = ms[0], ll = ls[0];
       f32x16 oa[2];
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 q4 = *reinterpret_cast<const f32x4*>(r0 + 4 + (mb * 2 + db) * 16 + 4 * g);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) oa[db][4 * g + e] = q4[e];
-        }
-      for (int w = 1; w < p.nsplit; ++w) {
-        const float* rw = p.parts + ((w * nchunk + cid) * 64 + lane) * 68;
-        const float mw = rw[mb];
+          for (int e = 0; e < 4; ++e) oa[db][4 * g + e] = os[0][db][g][e];
+#pragma unroll
+      for (int w = 1; w < MAXS; ++w) {
+        if (w >= p.nsplit) break;
+        const float mw = ms[w];
         const float mn = fmaxf(mm, mw);
         const float ca = (mm == -INFINITY) ? 0.f : __expf(mm - mn);
         const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-        ll = fmaf(ll, ca, rw[2 + mb] * cb);
+        ll = fmaf(ll, ca, ls[w] * cb);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(rw + 4 + (mb * 2 + db) * 16 + 4 * g);
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) oa[db][4 * g + e] = fmaf(oa[db][4 * g + e], ca, q4[e] * cb);
-          }
+            for (int e = 0; e < 4; ++e) oa[db][4 * g + e] = fmaf(oa[db][4 * g + e], ca, os[w][db][g][e] * cb);
         mm = mn;
       }
       const float inv = 1.0f / (ll + __shfl_xor(ll, 32, 64));
@@ -826,31 +855,44 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     load_x();
   }
   STAMP(4);
+  if (MODE == 2 && p.ws) {
+    // pass 2 of the split path: x after the projection (pass 1) + b2 + the MLP partials, in chunk order.  ALL the workspace
+    // loads (up to 5 per element quad, written by other CUs: every one a trip to the memory side) are issued before the first
+    // add -- as a load-add loop over the chunks they ran one round trip after the other, 13 k cycles of this 24 k-cycle kernel.
+    constexpr int MAXCH = 4;  // H <= 4 C, 256 hidden units per chunk
+    const int nch = p.H / Cfg<NMB>::HC;
+    f32x4 part[NMB][4][MAXCH + 1];
 #pragma unroll
-  for (int mb = 0; mb < NMB; ++mb) {
-    if (ATT == 4) break;  // (x was just computed)
-    const long long m = grow(mb * 32 + r);
+    for (int mb = 0; mb < NMB; ++mb) {
+      const long long m = grow(mb * 32 + r);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (MODE == 2 && p.ws) {  // x after the projection (pass 1) + b2 + the MLP partials, in chunk order
-        if (m >= 0) {
-          const long long o = m * C + wave * 32 + 8 * g + 4 * h;
-          xv = *reinterpret_cast<const f32x4*>(p.ws + o);
-          for (int sidx = 0; sidx < p.H / Cfg<NMB>::HC; ++sidx) {
-            const f32x4 pv = *reinterpret_cast<const f32x4*>(p.ws + (sidx + 1) * MC + o);
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] += pv[e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xv[e] += p.b2[wave * 32 + 8 * g + 4 * h + e];
-      } else {  // (MODE 2 without a workspace = mvt_ln_proj_bf16: x is final and only read; ws / b2 are null there)
-        xv = xr[mb][g];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += xv[e];
+        for (int sidx = 0; sidx <= MAXCH; ++sidx)
+          part[mb][g][sidx] = (m >= 0 && sidx <= nch) ? *reinterpret_cast<const f32x4*>(p.ws + ws_off(sidx, g)) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from sinking the loads back to their uses)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 xv = part[mb][g][0];
+#pragma unroll
+        for (int sidx = 1; sidx <= MAXCH; ++sidx)
+          if (sidx <= nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] += part[mb][g][sidx][e];
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += xv[e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
+      }
+  } else if (ATT != 4) {  // (MODE 2 without a workspace = mvt_ln_proj_bf16: x is final and only read; ws / b2 are null there)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += xr[mb][g][e];
   }
 
   // ---- 2. MLP: LayerNorm -> Xs, then chunks of HC hidden units.  x stays in registers: parking it in global memory
@@ -942,15 +984,14 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         if (m < 0) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const long long o = m * C + wave * 32 + 8 * g + 4 * h;
           f32x4 a4, x4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             a4[e] = acc2[mb][4 * g + e];
             x4[e] = v[mb][4 * g + e];
           }
-          *reinterpret_cast<f32x4*>(p.ws + (blockIdx.y + 1) * MC + o) = a4;
-          if (blockIdx.y == 0) *reinterpret_cast<f32x4*>(p.ws + o) = x4;
+          *reinterpret_cast<f32x4*>(p.ws + ws_off((int)blockIdx.y + 1, g)) = a4;
+          if (blockIdx.y == 0) *reinterpret_cast<f32x4*>(p.ws + ws_off(0, g)) = x4;
         }
       }
       return;
@@ -1115,7 +1156,7 @@ extern "C" int mvt_block_fused_bf16(float* x, int ldx, const void* att, int att_
   a.ws = workspace;
   if (nmb == 2) {
     hipLaunchKernelGGL((block_fused_bf16<2, 0, 0>), dim3((unsigned)mvt_cdiv(M, 64)), dim3(NT), 0, mvt_stream(stream), a);
-  } else if (workspace && !no_split && M <= 2048) {
+  } else if (workspace && !no_split && M <= 2048 && M % 32 == 0) {  // (whole 32-row tiles: the workspace is tile-native)
     MVT_REQUIRE((uintptr_t)workspace % 16 == 0);
     const unsigned tiles = (unsigned)mvt_cdiv(M, 32);
     hipLaunchKernelGGL((block_fused_bf16<1, 1, 0>), dim3(tiles, (unsigned)(H / 256)), dim3(NT), 0, mvt_stream(stream), a);
@@ -1160,7 +1201,7 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
     hipLaunchKernelGGL((block_fused_bf16<2, 0, 1>), dim3((unsigned)mvt_cdiv(M, a.bmv)), dim3(NT), 0, mvt_stream(stream), a);
   } else if (attn->kind == MVT_ATTN_PARTIALS) {
     // attention tile from the key-split partials (64 queries = the virtual tokens, frame = group): split path only
-    MVT_REQUIRE(attn->partials && attn->n_splits >= 1 && attn->n_splits <= 8 && attn->n_keys == 64 && M == 64LL * S);
+    MVT_REQUIRE(attn->partials && attn->n_splits >= 1 && attn->n_splits <= MVT_ATTN_NSPLIT && attn->n_keys == 64 && M == 64LL * S);
     MVT_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && M <= 2048 && (uintptr_t)attn->partials % 16 == 0);
     a.parts = attn->partials; a.nsplit = attn->n_splits;
     const unsigned tiles = (unsigned)mvt_cdiv(M, 32);
@@ -1169,7 +1210,8 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
     int maxblk = 1;
     for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
     const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
-    hipLaunchKernelGGL((block_fused_bf16<1, 2, 0>), dim3(tiles, slices), dim3(NT), 0, mvt_stream(stream), a);
+    (void)tiles;  // pass 2 on the SAME frame-major tiles (the workspace is tile-native)
+    hipLaunchKernelGGL((block_fused_bf16<1, 2, 5>), dim3(2, slices, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
   } else if (attn->kind == MVT_ATTN_FRAME) {
     MVT_REQUIRE(attn->n_keys >= 1 && attn->n_keys <= 64);
     const long long ntok = M / S;
@@ -1179,13 +1221,13 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
     } else {
       // few rows (the 64 virtual tracks): two-launch split path; pass 1 (frame-major tiles, attention recomputed by each of the
       // H / 256 chunk workgroups: it is tiny) leaves x and the MLP partials in the workspace by GLOBAL row, pass 2 is unchanged
-      MVT_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && M <= 2048);
-      hipLaunchKernelGGL((block_fused_bf16<1, 1, 2>), dim3((unsigned)mvt_cdiv(ntok, 32), (unsigned)(H / 256), (unsigned)S), dim3(NT), 0,
+      MVT_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && M <= 2048 && ntok % 32 == 0);  // (whole tiles: tile-native workspace)
+      hipLaunchKernelGGL((block_fused_bf16<1, 1, 2>), dim3((unsigned)(ntok / 32), (unsigned)(H / 256), (unsigned)S), dim3(NT), 0,
                          mvt_stream(stream), a);
       int maxblk = 1;
       for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
       const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
-      hipLaunchKernelGGL((block_fused_bf16<1, 2, 0>), dim3((unsigned)mvt_cdiv(M, 32), slices), dim3(NT), 0, mvt_stream(stream), a);
+      hipLaunchKernelGGL((block_fused_bf16<1, 2, 5>), dim3((unsigned)(ntok / 32), slices, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
     }
   } else {
     return MVT_ERR_ARG;

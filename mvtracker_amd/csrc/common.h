@@ -68,6 +68,13 @@ __device__ __forceinline__ void store_act4(float* base, long long off, const f32
   }
 }
 
+// Key-split attention partials in global memory (attention_mfma.hip writes, its merge variants and block_fused.hip's ATT 3 read):
+// one record per (split, chunk) = 17 quads x 64 lanes x 4 floats, QUAD-major, so that every access of a wave is one contiguous
+// 1-KiB piece (lane-major 68-float records made every load and store of a wave touch 64 different cache lines).  Quad 0 =
+// (m[0], m[1], l[0], l[1]); quad 1 + (mb*2 + db)*4 + g = accumulator registers 4g..4g+3 of O^T block (mb, db).
+#define MVT_PART_FLOATS (17 * 64 * 4)
+__device__ __forceinline__ long long mvt_part_off(long long rec, int quad, int lane) { return (rec * 17 + quad) * 256 + lane * 4; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
