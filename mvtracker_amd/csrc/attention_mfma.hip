@@ -36,11 +36,13 @@ __device__ __forceinline__ bf16x8 load8(const float* base, long long off, int bf
   return o;
 }
 
-template <int KS>
+// (BFIN: bf16 q / k / v tensors -- a compile-time flag: as a run-time one every load sat in its own branch with its own full wait)
+template <int KS, bool BFIN>
 __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel(
     const float* __restrict__ q, int ldq, long long q_gs, long long q_is, const float* __restrict__ k, const float* __restrict__ v,
-    int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads, int bf_in,
+    int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads, int bf_in_unused,
     int bf_out, float* __restrict__ ws, unsigned* __restrict__ tickets) {
+  constexpr int bf_in = BFIN ? 1 : 0;
   // ws != null: the keys are additionally cut over gridDim.y workgroups; wave 0 leaves its (m, l, O) partial in ws and
   // attention_merge_kernel finishes the softmax (the 64 virtual x 1024 point attention is only 72 (frame, head) chunks)
   constexpr int NW = KS == 1 ? 4 : KS;
@@ -61,6 +63,40 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
   const int qc = (int)(cid % chunks);
   const int hd = (int)((cid / chunks) % heads);
   const long long g = cid / ((long long)chunks * heads);
+
+  const int nkb = (nk + 31) / 32;                       // key blocks
+  const int gper = ws ? (nkb + (int)gridDim.y - 1) / (int)gridDim.y : nkb;   // ... of this workgroup
+  const int g0 = ws ? (int)blockIdx.y * gper : 0;
+  const int g1 = g0 + gper < nkb ? g0 + gper : nkb;
+  const int per = (gper + KS - 1) / KS;
+  const int kb0 = KS == 1 ? g0 : g0 + wave * per;
+  const int kb1 = KS == 1 ? g1 : (kb0 + per < g1 ? kb0 + per : g1);
+  const long long kvbase = (g * k_gs) * ldkv + hd * DH;  // element offset (fp32 or bf16 tensors)
+  const long long kstep = k_is * ldkv;
+  // K / V operands of one 32-key block as they come from memory: the block after the current one is always in flight (and the
+  // first one is requested ahead of the Q conversion), so a wave pays one memory round trip, not one per key block
+  struct KV {
+    bf16x8 kf[3];   // A fragments: key row r, k = d
+    f32x4 vraw[6];  // V[key][24h + 4i .. +3]: fp32 values, or (bf16 tensors) the two packed words in [0], [1]
+  };
+  auto load_kv = [&](int kb, KV& t) {
+    const int key = kb * 32 + r;
+    const long long ko = kvbase + (long long)(key < nk ? key : nk - 1) * kstep;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) t.kf[ks] = load8(k, ko + ks * 16 + 8 * h, bf_in);
+    const long long vo = ko + 24 * h;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (bf_in) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(v) + vo + 4 * i);
+        t.vraw[i] = (f32x4){__uint_as_float(w.x), __uint_as_float(w.y), 0.f, 0.f};
+      } else {
+        t.vraw[i] = *reinterpret_cast<const f32x4*>(v + vo + 4 * i);
+      }
+    }
+  };
+  KV cur;
+  if (kb0 < kb1) load_kv(kb0, cur);
 
   // Q^T fragments (B operand): lane (r, h) of block mb holds Q[query qc*64 + mb*32 + r][ks*16 + 8h ..], pre-scaled
   const float scale = 1.0f / sqrtf((float)DH);
@@ -101,33 +137,27 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
       for (int e = 0; e < 16; ++e) oacc[mb][db][e] = 0.f;
   }
 
-  const int nkb = (nk + 31) / 32;                       // key blocks
-  const int gper = ws ? (nkb + (int)gridDim.y - 1) / (int)gridDim.y : nkb;   // ... of this workgroup
-  const int g0 = ws ? (int)blockIdx.y * gper : 0;
-  const int g1 = g0 + gper < nkb ? g0 + gper : nkb;
-  const int per = (gper + KS - 1) / KS;
-  const int kb0 = KS == 1 ? g0 : g0 + wave * per;
-  const int kb1 = KS == 1 ? g1 : (kb0 + per < g1 ? kb0 + per : g1);
-  const long long kvbase = (g * k_gs) * ldkv + hd * DH;  // element offset (fp32 or bf16 tensors)
-  const long long kstep = k_is * ldkv;
-
 #pragma unroll 1
   for (int kb = kb0; kb < kb1; ++kb) {
+    KV nxt = cur;
+    if (kb + 1 < kb1) load_kv(kb + 1, nxt);
     // ---- K block: A fragments (key row r of this block, k = d)
     const int key = kb * 32 + r;
-    const long long ko = kvbase + (long long)(key < nk ? key : nk - 1) * kstep;
     bf16x8 kf[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) kf[ks] = load8(k, ko + ks * 16 + 8 * h, bf_in);
+    for (int ks = 0; ks < 3; ++ks) kf[ks] = cur.kf[ks];
     // ---- V block -> transposed LDS image vt[d][key]: lane handles key (lane & 31), d range 24 * (lane >> 5) .. +23
     {
-      const long long vo = ko + 24 * h;
       // (the image is written as 16-bit elements and read back as 32-bit vectors: a wavefront-scope fence keeps the
       //  compiler's type-based alias analysis from reordering the two)
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        f32x4 a = load_act4(v, vo + 4 * i, bf_in);
+        f32x4 a = cur.vraw[i];
+        if (bf_in) {
+          const unsigned wx = __float_as_uint(a[0]), wy = __float_as_uint(a[1]);
+          a = (f32x4){__uint_as_float(wx << 16), __uint_as_float(wx & 0xFFFF0000u), __uint_as_float(wy << 16), __uint_as_float(wy & 0xFFFF0000u)};
+        }
         if (key >= nk) a = (f32x4){0.f, 0.f, 0.f, 0.f};
         // (16-bit element extraction from the packed bf16 vector is done on the 32-bit words: hipcc 7.2 emits
         //  ds_write_b16 of the same low half for every element of `b[e]` otherwise)
@@ -194,6 +224,7 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
         }
       }
     }
+    cur = nxt;
   }
 
   if (KS > 1) {
@@ -413,9 +444,14 @@ extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long l
   MVT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= heads * dh && ldkv >= heads * dh && ldo >= heads * dh);
   MVT_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 16 == 0));
   const long long nchunk = (long long)groups * heads * ((nq + 63) / 64);
-#define LAUNCH(KS, BLOCKS, THREADS)                                                                                        \
-  hipLaunchKernelGGL((attention_mfma_kernel<KS>), dim3((unsigned)(BLOCKS)), dim3(THREADS), 0, mvt_stream(stream), (const float*)q, ldq, q_gs, \
-                     q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out, WS, nullptr)
+#define LAUNCH_T(KS, BF, BLOCKS, THREADS, WSP, TK)                                                                                    \
+  hipLaunchKernelGGL((attention_mfma_kernel<KS, BF>), BLOCKS, dim3(THREADS), 0, mvt_stream(stream), (const float*)q, ldq, q_gs, q_is, \
+                     (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out, WSP, TK)
+#define LAUNCH(KS, BLOCKS, THREADS)                                         \
+  do {                                                                      \
+    if (bf_in) LAUNCH_T(KS, true, dim3((unsigned)(BLOCKS)), THREADS, WS, nullptr);  \
+    else LAUNCH_T(KS, false, dim3((unsigned)(BLOCKS)), THREADS, WS, nullptr);       \
+  } while (0)
   constexpr int NSPLIT = MVT_ATTN_NSPLIT;
   MVT_REQUIRE(!partials_only || (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0 && !fused_merge));
   if (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0) {
@@ -423,9 +459,8 @@ extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long l
     MVT_REQUIRE((uintptr_t)workspace % 16 == 0);
 #define WS workspace
     unsigned* tickets = fused_merge ? reinterpret_cast<unsigned*>(workspace + (long long)NSPLIT * nchunk * 64 * 68) : nullptr;
-    hipLaunchKernelGGL((attention_mfma_kernel<4>), dim3((unsigned)nchunk, NSPLIT), dim3(256), 0, mvt_stream(stream), (const float*)q, ldq,
-                       q_gs, q_is, (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out,
-                       workspace, tickets);
+    if (bf_in) LAUNCH_T(4, true, dim3((unsigned)nchunk, NSPLIT), 256, workspace, tickets);
+    else LAUNCH_T(4, false, dim3((unsigned)nchunk, NSPLIT), 256, workspace, tickets);
 #undef WS
     if (!fused_merge && !partials_only)
       hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)mvt_cdiv(nchunk, 4)), dim3(256), 0, mvt_stream(stream), workspace, NSPLIT,
@@ -440,5 +475,6 @@ extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long l
   }
 #undef WS
 #undef LAUNCH
+#undef LAUNCH_T
   return mvt_launch_status();
 }
