@@ -24,6 +24,25 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Diagnostic build only (-DMVT_STAMPS, tools/stamp_conv.py): s_memtime at the phase boundaries of two workgroups, one slot per
+// (workgroup, wave, stamp), in a buffer of its own.  No stamp executes in the shipped library.
+#ifdef MVT_STAMPS
+__device__ unsigned long long mvt_conv_stamp_buf[2 * 4 * 128];
+#define CSTAMP(i)                                                                                                  \
+  do {                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    unsigned long long t_;                                                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 2000) && (i) < 128)                           \
+      mvt_conv_stamp_buf[((blockIdx.x ? 1 : 0) * 4 + (threadIdx.x >> 6)) * 128 + (i)] = t_;                        \
+  } while (0)
+#else
+#define CSTAMP(i) \
+  do {            \
+  } while (0)
+#endif
+
 struct RowsArgs {
   const float* in;   // [n][H][W][Cin] fp32 or bf16
   const unsigned short* w;  // bf16 [Cout][ldw]: row = (kh, kw, cin)
@@ -322,11 +341,6 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
       for (int i = 0; i < NPL; ++i) rp[i] = *reinterpret_cast<const f32x4*>(p.in + in_img + pg[i] + c0);
     }
   };
-  // InstanceNorm statistics: staged in LDS once (they would otherwise occupy 16 registers through the MFMA loop)
-  if (p.in_stats) {
-    for (int i = t; i < 2 * p.Cin; i += NT) Sst[i] = p.in_stats[img * 2 * p.Cin + i];
-    __syncthreads();
-  }
   auto norm4 = [&](f32x4 v, const f32x4& m, const f32x4& rs) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - m[e]) * rs[e], 0.f);
@@ -390,6 +404,15 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
     }
   };
 
+  // the first patch chunk and weight stage are requested before anything waits: their round trip passes under the statistics
+  // staging and its barrier
+  load_patch(0);
+  load_w(0, 0);
+  // InstanceNorm statistics: staged in LDS once (they would otherwise occupy 16 registers through the MFMA loop)
+  if (p.in_stats) {
+    for (int i = t; i < 2 * p.Cin; i += NT) Sst[i] = p.in_stats[img * 2 * p.Cin + i];
+    __syncthreads();
+  }
   const int lane = t & 63;
   const int wm = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -407,15 +430,17 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
 
   for (int i = t; i < G::ROWS * BN * 2; i += NT) wst[i] = 0.f;  // (rows past the image stay zero; the loop's barriers order this)
   const int nchunk = p.Cin / CK;
-  load_patch(0);
-  load_w(0, 0);
+  CSTAMP(0);
   for (int c = 0; c < nchunk; ++c) {
+    CSTAMP(1 + 8 * c);
     store_patch(c * CK);  // (the barrier that ended the previous chunk's last stage made the patch free)
+    CSTAMP(2 + 8 * c);
     const bool more = c + 1 < nchunk;
 #pragma unroll
     for (int kh = 0; kh < KS; ++kh) {
       store_w();
       __syncthreads();
+      CSTAMP(3 + 8 * c + 2 * kh);
       if (kh + 1 < KS) {
         load_w(c * CK, kh + 1);
       } else if (more) {
@@ -440,9 +465,11 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
       }
+      CSTAMP(4 + 8 * c + 2 * kh);
       __syncthreads();
     }
   }
+  CSTAMP(120);
 
   // ---- epilogue: D[pixel][cout]: cout on the lanes, pixels (e&3) + 8(e>>2) + 4h in the registers.  A row's address is a
   // wave-uniform base (SGPRs) plus one 32-bit lane offset.  Neighbouring lanes hold neighbouring channels of the same
@@ -452,10 +479,12 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
   // (the loop above ended with a barrier: patch and weights are dead, the staging tiles reuse their LDS)
   epilogue_rows<TM, TN, TN == 3, STAGED>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, n0, tiles_x, tx, lane, Ps + wm * stage_elems<TN>(), wst,
                                          wm * TM);
+  CSTAMP(121);
   if (p.out_part) {
     __syncthreads();
     write_tile_stats<G::ROWS, BN>(p, wst, img, ty * tiles_x + tx, n0, t);
   }
+  CSTAMP(122);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,6 +588,16 @@ __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
 }
 
 }  // namespace
+
+#ifdef MVT_STAMPS
+extern "C" int mvt_debug_read_conv_stamps(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(mvt_conv_stamp_buf), sizeof(unsigned long long) * 2 * 4 * 128) == hipSuccess ? MVT_OK : MVT_ERR_HIP_BASE;
+}
+extern "C" int mvt_debug_clear_conv_stamps() {
+  static unsigned long long z[2 * 4 * 128];
+  return hipMemcpyToSymbol(HIP_SYMBOL(mvt_conv_stamp_buf), z, sizeof(z)) == hipSuccess ? MVT_OK : MVT_ERR_HIP_BASE;
+}
+#endif
 
 // tile rows of the variant the launcher picks for (kernel size, stride) -- shared with mvt_conv2d_stat_slots
 static int rows_nw8() {
