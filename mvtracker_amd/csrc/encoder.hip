@@ -340,6 +340,65 @@ __global__ void concat_resize_kernel(ConcatSrc cs, float* __restrict__ dst, int 
   }
 }
 
+// bf16 form of the same concat (one block per output image row, grid.y = image): a thread keeps ONE channel octet -- its source
+// map, channel offset and vertical taps are fixed for the whole row -- and walks the pixels; 16-byte loads of the four taps, no
+// division in the loop (the generic kernel above pays three 32-bit divisions and eight 8-byte loads per piece).
+__global__ __launch_bounds__(256) void concat_resize_rows_bf16_kernel(ConcatSrc cs, unsigned short* __restrict__ dst, int Hd, int Wd, int ldd) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int ctot = cs.c0[cs.nsrc - 1] + cs.C[cs.nsrc - 1];
+  const int ppr = ctot >> 3;                  // octets per pixel
+  const int pstep = 256 / ppr;                // pixels per sweep of the block
+  const int t = threadIdx.x;
+  if (t >= pstep * ppr) return;
+  const int oc = t % ppr, px0 = t / ppr;
+  const int ch = oc * 8;
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (k < cs.nsrc && ch >= cs.c0[k]) s = k;
+  const int Hs = cs.Hs[s], Ws = cs.Ws[s], C = cs.C[s];
+  const unsigned short* src = reinterpret_cast<const unsigned short*>(cs.p[s]);
+  const int y = blockIdx.x;
+  const long long img = blockIdx.y;
+  const float rh = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
+  const float rw = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+  const float fy = rh * y;
+  const int y0 = (int)fy;
+  const int yp = y0 < Hs - 1 ? 1 : 0;
+  const float ly = fy - y0, hy = 1.f - ly;
+  const unsigned short* r0 = src + ((img * Hs + y0) * (long long)Ws) * C + (ch - cs.c0[s]);
+  const unsigned short* r1 = r0 + (long long)yp * Ws * C;
+  unsigned short* drow = dst + ((img * Hd + y) * (long long)Wd) * ldd + ch;
+  auto unpack = [](const u32x4& w, float (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = __uint_as_float(w[e] << 16);
+      f[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u);
+    }
+  };
+  for (int x = px0; x < Wd; x += pstep) {
+    const float fx = rw * x;
+    const int x0 = (int)fx;
+    const int xp = x0 < Ws - 1 ? 1 : 0;
+    const float lx = fx - x0, hx = 1.f - lx;
+    const u32x4 w00 = *reinterpret_cast<const u32x4*>(r0 + (long long)x0 * C), w01 = *reinterpret_cast<const u32x4*>(r0 + (long long)(x0 + xp) * C);
+    const u32x4 w10 = *reinterpret_cast<const u32x4*>(r1 + (long long)x0 * C), w11 = *reinterpret_cast<const u32x4*>(r1 + (long long)(x0 + xp) * C);
+    float a00[8], a01[8], a10[8], a11[8];
+    unpack(w00, a00);
+    unpack(w01, a01);
+    unpack(w10, a10);
+    unpack(w11, a11);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v0 = hy * (hx * a00[2 * e] + lx * a01[2 * e]) + ly * (hx * a10[2 * e] + lx * a11[2 * e]);
+      const float v1 = hy * (hx * a00[2 * e + 1] + lx * a01[2 * e + 1]) + ly * (hx * a10[2 * e + 1] + lx * a11[2 * e + 1]);
+      o[e] = (unsigned)mvt_bf16_bits(v0) | ((unsigned)mvt_bf16_bits(v1) << 16);
+    }
+    *reinterpret_cast<u32x4*>(drow + (long long)x * ldd) = o;
+  }
+}
+
 inline unsigned grid_for(long long total, int block = 256) {
   long long g = mvt_cdiv(total, block);
   return (unsigned)(g > 256 * 32 ? 256 * 32 : (g < 1 ? 1 : g));
@@ -364,7 +423,11 @@ extern "C" int mvt_concat_resize_bilinear_ac(int nsrc, const void* const* srcs, 
   MVT_REQUIRE(ldd >= c0 && ldd % E == 0 && ((uintptr_t)dst % 16 == 0));
   const long long total = (long long)n * Hd * Wd * (c0 / E);
   MVT_REQUIRE(total < (1LL << 31));
-  if (bf)
+  static const bool generic = getenv("MVT_CONCAT_GENERIC") != nullptr;  // tuning / A-B switch
+  if (bf && !generic && c0 / 8 <= 256 && n <= 65535)
+    hipLaunchKernelGGL(concat_resize_rows_bf16_kernel, dim3((unsigned)Hd, (unsigned)n), dim3(256), 0, mvt_stream(stream), cs,
+                       (unsigned short*)dst, Hd, Wd, ldd);
+  else if (bf)
     hipLaunchKernelGGL(concat_resize_kernel<1>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), cs, (float*)dst, n, Hd, Wd, ldd);
   else
     hipLaunchKernelGGL(concat_resize_kernel<0>, dim3(grid_for(total)), dim3(256), 0, mvt_stream(stream), cs, (float*)dst, n, Hd, Wd, ldd);
