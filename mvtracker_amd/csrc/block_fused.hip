@@ -479,9 +479,11 @@ __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int 
 
 // LayerNorm of the 128 x C tile held as accumulators v[4][16] (wave w: channels w*32 .. +31 of every token), written
 // as bf16 into Xs.  st: LDS scratch [8 waves][128 tokens][2].  Optional affine (wave's channel slice).
+// ms: (mean, biased variance) of every token block of this lane's token -- computed here unless `have` (the follow-up projections
+// of a block normalise the same x with different eps / affine: the statistics exchange and its barrier run once).
 template <int NMB>
 __device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short* Xs, float* st, int wave, int lane, float eps,
-                                          const float* lnw, const float* lnb) {
+                                          const float* lnw, const float* lnb, float (&ms)[NMB][2], bool have) {
   constexpr int BM = 32 * NMB;
   const int r = lane & 31, h = lane >> 5;
   // the affine parameters of this wave's channel slice are requested first: their memory round trip passes under the statistics
@@ -494,32 +496,40 @@ __device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short
       gb[g] = *reinterpret_cast<const f32x4*>(lnb + wave * 32 + 8 * g + 4 * h);
     }
   }
+  if (!have) {  // (workgroup-uniform)
 #pragma unroll
-  for (int mb = 0; mb < NMB; ++mb) {
-    float s1 = 0.f, s2 = 0.f;
+    for (int mb = 0; mb < NMB; ++mb) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      s1 += v[mb][e];
-      s2 = fmaf(v[mb][e], v[mb][e], s2);
+      for (int e = 0; e < 16; ++e) {
+        s1 += v[mb][e];
+        s2 = fmaf(v[mb][e], v[mb][e], s2);
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        st[(wave * BM + mb * 32 + r) * 2] = s1;
+        st[(wave * BM + mb * 32 + r) * 2 + 1] = s2;
+      }
     }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (h == 0) {
-      st[(wave * BM + mb * 32 + r) * 2] = s1;
-      st[(wave * BM + mb * 32 + r) * 2 + 1] = s2;
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        s1 += st[(w * BM + mb * 32 + r) * 2];
+        s2 += st[(w * BM + mb * 32 + r) * 2 + 1];
+      }
+      const float mean = s1 / (float)C;
+      ms[mb][0] = mean;
+      ms[mb][1] = fmaxf(s2 / (float)C - mean * mean, 0.f);
     }
   }
-  __syncthreads();
 #pragma unroll
   for (int mb = 0; mb < NMB; ++mb) {
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      s1 += st[(w * BM + mb * 32 + r) * 2];
-      s2 += st[(w * BM + mb * 32 + r) * 2 + 1];
-    }
-    const float mean = s1 / (float)C;
-    const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)C - mean * mean, 0.f) + eps);
+    const float mean = ms[mb][0];
+    const float rstd = 1.0f / sqrtf(ms[mb][1] + eps);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = wave * 32 + 8 * g + 4 * h;
@@ -913,7 +923,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     }
   };
   STAMP(5);
-  if (HAS_MLP) ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr);  // ends with a barrier: Hs is free again
+  float ln_ms[NMB][2];
+  if (HAS_MLP) ln_to_lds<NMB>(v, Xs, st, wave, lane, 1e-6f, nullptr, nullptr, ln_ms, false);  // ends with a barrier: Hs is free again
   STAMP(6);
   const bool tail_next = MODE == 0 && active(0) && wave < (p.next[0].N + 31) / 32;
   if (HAS_MLP) {
@@ -1010,6 +1021,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
   bool have = tail_next || early_have;  // the queue already holds this wave's first block of the projection
+  bool have_ms = false;
 #pragma unroll
   for (int q = 0; q < MVT_BLOCK_MAX_NEXT; ++q) {  // static indices: a dynamically indexed kernel-argument array would live in scratch
     if (q >= p.n_next) break;
@@ -1020,7 +1032,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     // behind the 16 queued fragment loads in the in-order vmcnt counter and expose their whole latency every block
     for (int i = t; i < nx.N; i += NT) b1s[i] = nx.b[i];
     STAMP(32 + 8 * q);
-    ln_to_lds<NMB>(v, Xs, st, wave, lane, nx.eps, nx.lnw, nx.lnb);
+    ln_to_lds<NMB>(v, Xs, st, wave, lane, nx.eps, nx.lnw, nx.lnb, ln_ms, have_ms);
+    have_ms = true;  // (x does not change any more: the next projection reuses the statistics)
     STAMP(33 + 8 * q);
     const int nblocks = (nx.N + 31) / 32;
     auto nrow_of = [&](int nb) { return nx.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };

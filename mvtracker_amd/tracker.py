@@ -132,6 +132,7 @@ class MVTracker(nn.Module):
         # launch (all variants are bit-identical to the separate launches)
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
+        self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
         self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
         self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
         self.fuse_tokens = os.environ.get("MVT_FUSE_TOKENS", "1") != "0"  # ... with the token rows assembled inside that launch
@@ -521,7 +522,7 @@ class MVTracker(nn.Module):
         hs, ws = H // self.stride, W // self.stride
         fv = store["fvec"]
         if level0 is None:
-            self.encode_frames(rgbs, a, b, images_per_chunk=max(16, V * (self.S // 2)), out=fv[0])
+            self.encode_frames(rgbs, a, b, images_per_chunk=self.encoder_chunk_images or max(16, V * (self.S // 2)), out=fv[0])
         for lvl in range(1, self.corr_n_levels):
             h, w = hs >> (lvl - 1), ws >> (lvl - 1)
             hip.avgpool2(fv[lvl - 1][a:b], fv[lvl][a:b], (b - a) * V, h, w, self.latent_dim)
