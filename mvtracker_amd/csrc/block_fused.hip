@@ -249,15 +249,13 @@ __device__ __forceinline__ void gemm_wq(f32x16 (&acc)[NMB], bf16x8 (&wq)[PFQ], c
     }
   }
 }
-// The attention output projection (Ko = 288: 18 k-steps) on the same queue: fragments 0..15 in wq -- requested long
+// The attention output projection (Ko = 288: 18 k-steps) on the same queue: fragments 0..15 in wq, 16 and 17 in wx (requested by the caller just ahead of the tile's x rows) -- the queue is requested long
 // before (ahead of / inside the attention phase), so the projection starts on resident operands instead of paying a memory round
 // trip per four k-steps -- and, with REFILL, the queue leaves holding the first 16 fragments of the stream nxt (the MLP's fc1).
 template <int NMB, bool REFILL>
-__device__ __forceinline__ void gemm_wq18(f32x16 (&acc)[NMB], bf16x8 (&wq)[PFQ], const unsigned short* wrow, const unsigned short* nxt,
+__device__ __forceinline__ void gemm_wq18(f32x16 (&acc)[NMB], bf16x8 (&wq)[PFQ], const bf16x8 (&wx)[2], const unsigned short* nxt,
                                           const unsigned short* arow, int lda) {
   constexpr int KS = 18, GK = 2;
-  // (the last two fragments are requested here: sixteen k-steps of MFMAs pass before they are needed)
-  const bf16x8 wx[2] = {ldg_frag(wrow + 16 * FS), ldg_frag(wrow + 17 * FS)};
   bf16x8 xa[GK][NMB], xn[GK][NMB];
 #pragma unroll
   for (int j = 0; j < GK; ++j)
@@ -648,6 +646,16 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     }
   };
 
+  // ahead of the barrier that ends the attention / staging phase: the last two projection fragments, then the x rows (in this order:
+  // loads return in order, and the fragments are needed first) -- the waves that arrive last at the barrier are the critical path,
+  // and for them the x rows' round trip now passes under the projection GEMM instead of following it
+  bf16x8 wx[2];
+  auto pre_gemm = [&]() {
+    wx[0] = ldg_frag(wo_row + 16 * FS);
+    wx[1] = ldg_frag(wo_row + 17 * FS);
+    load_x();
+  };
+
   // ---- 1. attention output projection (accumulated into v, x is added afterwards)
   if (MODE == 3 && ATT == 4) {
     // Input transform (cotracker2/blocks.py:456-459): the residual stream x is BORN here.  The 581-wide token rows (padded to
@@ -763,9 +771,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
           }
         }
     }
+    pre_gemm();
     __syncthreads();
-    load_x();
-    gemm_wq18<NMB, HAS_MLP>(v, wq, wo_row, fc1_first, &As[r * LDA + 8 * h], LDA);
+    gemm_wq18<NMB, HAS_MLP>(v, wq, wx, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
@@ -825,11 +833,11 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, lane);
       attn_compute<NMB, 2>(fr, nq, p.nkeys, wave, vt, zrow, As, LDA, 0, lane);
     }
+    pre_gemm();
     STAMP(2);
     __syncthreads();
     STAMP(3);
-    load_x();
-    gemm_wq18<NMB, HAS_MLP>(v, wq, wo_row, fc1_first, &As[r * LDA + 8 * h], LDA);
+    gemm_wq18<NMB, HAS_MLP>(v, wq, wx, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
@@ -852,11 +860,11 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
       *reinterpret_cast<u32x2*>(&As[row * LDA + c]) = w;
     }
+    pre_gemm();
     STAMP(2);
     __syncthreads();
     STAMP(3);
-    load_x();
-    gemm_wq18<NMB, HAS_MLP>(v, wq, wo_row, fc1_first, &As[r * LDA + 8 * h], LDA);
+    gemm_wq18<NMB, HAS_MLP>(v, wq, wx, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll

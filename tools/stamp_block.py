@@ -92,6 +92,8 @@ for q in range(3):
     for b in range(5):
         names[34 + 8 * q + b] = f"p{q} blk{b}"
 for wg in range(2):
+    if not (buf[wg] > 0).any():
+        continue
     t0 = buf[wg][buf[wg] > 0].min()
     print(f"workgroup {'0' if wg == 0 else '100'}: cycles since the first stamp / delta, per wave")
     idx = [i for i in range(64) if (buf[wg, :, i] > 0).any()]
