@@ -327,7 +327,8 @@ int mvt_knn_merge_levels(int levels, const mvt_knn_level* lv, int N, int S, int 
 /* Seeded scan + merge of all levels in ONE launch: every (track, slot) is searched by a single wave over the whole cloud
  * (tile boxes required; nseg and keys are ignored) and its K neighbour indices go straight to idx_out -- the result of
  * mvt_knn_scan_levels + mvt_knn_merge_levels, bit for bit (exact kNN, ties by index).  idx_out may alias seed_idx: a wave reads
- * the seeds of its own entries before it writes them.  seed_k >= K. */
+ * the seeds of its own entries before it writes them.  seed_k >= K, or seed_k == 0 with every seed_idx NULL: unseeded searches
+ * (the initial threshold is the farthest-corner bound of the nearest tile with >= K finite points). */
 int mvt_knn_search_levels(int levels, const mvt_knn_level* lv, const float* coords, int N, int S, int frame0, int frame_step,
                           int T, int K, int seed_k, void* stream);
 /* Gather-dot correlation for `levels` pyramid levels in ONE launch (grid.y = level).  Host arrays of per-level

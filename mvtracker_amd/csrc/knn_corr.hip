@@ -761,11 +761,11 @@ extern "C" int mvt_knn_merge_levels(int levels, const mvt_knn_level* lv, int N, 
 extern "C" int mvt_knn_search_levels(int levels, const mvt_knn_level* lv, const float* coords, int N, int S, int frame0, int frame_step,
                                      int T, int K, int seed_k, void* stream) {
   MVT_REQUIRE(levels >= 1 && levels <= 8 && lv && coords && N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0);
-  MVT_REQUIRE(K >= 1 && K <= 16 && seed_k >= K && seed_k <= 64);
+  MVT_REQUIRE(K >= 1 && K <= 16 && (seed_k == 0 || (seed_k >= K && seed_k <= 64)));
   KnnLevels a{};
   for (int l = 0; l < levels; ++l) {
     const mvt_knn_level& L = lv[l];
-    MVT_REQUIRE(L.xyz && L.seed_idx && L.idx_out && L.tile_box && L.P >= K && L.P < (1LL << 31));
+    MVT_REQUIRE(L.xyz && L.idx_out && L.tile_box && L.P >= K && L.P < (1LL << 31) && (L.seed_idx != nullptr) == (seed_k > 0));
     MVT_REQUIRE((L.grid_w == 0 && L.grid_h == 0) ||
                 (L.grid_w > 0 && L.grid_h > 0 && L.grid_w % 8 == 0 && L.grid_h % 8 == 0 && L.P % ((long long)L.grid_w * L.grid_h) == 0));
     a.lv[l] = L;

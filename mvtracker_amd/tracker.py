@@ -856,7 +856,13 @@ class MVTracker(nn.Module):
                     else:
                         hip.knn_scan_levels(lv0, coords, n0, S, frame0, 1, T, K, seed_k=K)
                         hip.knn_merge_levels(lv0, n0, S, K)
-                if n0 < n:  # new tracks: coarse to fine, level l+1's neighbours bound level l's first scan
+                if n0 < n and self.knn_one_launch and all(b is not None for b in store["box"]):
+                    # new tracks: all four levels in ONE unseeded launch (every search starts from the farthest-corner bound of the
+                    # nearest full tile) -- 262 us against four dependent coarse-to-fine launches of ~100 us each
+                    m = n - n0
+                    lv1 = [dict(lv, seed_idx=None, idx_out=idx[l_][n0:]) for l_, lv in enumerate(levels)]
+                    hip.knn_search_levels(lv1, coords[n0:], m, S, frame0, 1, T, K, seed_k=0)
+                elif n0 < n:  # new tracks: coarse to fine, level l+1's neighbours bound level l's first scan
                     m = n - n0
                     for lvl in reversed(range(L)):
                         P = store["P"][lvl]

@@ -327,6 +327,7 @@ def knn_search(xyz, Pn, coords, N, S, frame0, frame_step, T, K, idx_out, box, gr
 
 def knn_search_levels(levels, coords, N, S, frame0, frame_step, T, K, seed_k):
     for lv in levels:
+        assert (lv.get("seed_idx") is not None) == (seed_k > 0)
         keys = torch.empty(N * S * K, dtype=torch.int64, device=coords.device)
         knn_scan(lv["xyz"], lv["P"], coords, N, S, frame0, frame_step, T, K, 1, keys, seed_idx=lv.get("seed_idx"), seed_k=seed_k,
                  box=lv.get("box"), grid=lv.get("grid", (0, 0)))

@@ -725,6 +725,13 @@ def test_knn_levels_one_launch(hip):
     torch.cuda.synchronize()
     for a, b in zip(ref2, inpl):
         assert torch.equal(a, b)
+    # ... and unseeded (seed_k = 0): the same neighbours again
+    outs = [torch.empty(M, B, K, device=DEV, dtype=torch.int32) for _ in grids]
+    lv = [dict(xyz=clouds[l], P=V * h * w, seed_idx=None, box=boxes[l], grid=(w, h), idx_out=outs[l], gbox=gbs[l]) for l, (h, w) in enumerate(grids)]
+    hip.knn_search_levels(lv, q, M, B, 0, 1, B, K, seed_k=0)
+    torch.cuda.synchronize()
+    for a, b in zip(ref2, outs):
+        assert torch.equal(a, b)
 
 
 def test_corr_all_levels_one_launch(hip):

@@ -51,4 +51,22 @@ def run(sel):
     return min(ts[1:])
 
 
+
+
+def run_unseeded(sel):
+    lvs = [dict(xyz=levels[i]["xyz"], P=levels[i]["P"], box=levels[i]["box"], grid=levels[i]["grid"], seed_idx=None, gbox=levels[i]["gbox"],
+                idx_out=torch.empty(N, S, K, device=dev, dtype=torch.int32)) for i in sel]
+    ts = []
+    for rep in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            hip.knn_search_levels(lvs, q2, N, S, 0, 1, T, K, 0)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 200)
+    return min(ts[1:])
+
+
+print(f"unseeded: all levels {run_unseeded([0, 1, 2, 3]):.1f} us; " + "  ".join(f"L{i} {run_unseeded([i]):.1f}" for i in range(4)))
 print(f"Q={os.environ.get('MVT_KNN_Q', '2')}: all levels {run([0, 1, 2, 3]):.1f} us; " + "  ".join(f"L{i} {run([i]):.1f}" for i in range(4)))
