@@ -112,28 +112,6 @@ struct BlockArgs {
   int t_E, t_Fc, t_Cf, t_D;
 };
 
-// one element of the updater's input token (mvtracker.py:379-387): [sin|cos flow embedding 3E | flow 3 | fcorr Fc | ffeats Cf |
-// track mask, visibility 2] + positional + time embedding -- the same expressions, in the same order, as token_assemble_kernel
-__device__ __forceinline__ float token_elem(const BlockArgs& p, long long row, int n, int sidx, int d, const float (&fl)[3]) {
-  const int E = p.t_E, Fc = p.t_Fc, Cf = p.t_Cf;
-  float v;
-  if (d < 3 * E) {
-    const int a = d / E, w = d - a * E;
-    const float div = (float)(w & ~1) * (1000.0f / (float)E);
-    const float arg = fl[a] * div;
-    v = (w & 1) ? cosf(arg) : sinf(arg);
-  } else if (d < 3 * E + 3) {
-    v = fl[d - 3 * E];
-  } else if (d < 3 * E + 3 + Fc) {
-    v = p.t_fcorr[row * Fc + (d - 3 * E - 3)];
-  } else if (d < 3 * E + 3 + Fc + Cf) {
-    v = p.t_ffeats[row * Cf + (d - 3 * E - 3 - Fc)];
-  } else {
-    v = p.t_maskvis[row * 2 + (d - 3 * E - 3 - Fc - Cf)];
-  }
-  return (v + p.t_pos[(long long)n * p.t_D + d]) + p.t_time[(long long)sidx * p.t_D + d];
-}
-
 // gelu_tanh on a pair: x * sigmoid(2k), k = sqrt(2/pi) (x + 0.044715 x^3), as x / (1 + exp2(x (c0 + c1 x^2))) with
 // c0 = -2 sqrt(2/pi) log2(e), c1 = 0.044715 c0.  Packed fp32 ops (v_pk_mul / v_pk_fma / v_pk_add) carry two values per
 // instruction; only v_exp_f32 / v_rcp_f32 are per value: ~26 instead of ~46 issue cycles per value -- the fc1 epilogue was VALU-bound
@@ -677,20 +655,66 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
           if (m >= 0 && m < p.Mp && k0 + c < p.ldtok)
             w = __builtin_bit_cast(u32x2, __builtin_convertvector(*reinterpret_cast<const f32x4*>(p.tokx + m * (long long)p.ldtok + k0 + c), bf16x4));
         } else if (m >= 0 && m < p.Mp && k0 + c < p.t_D) {  // assemble the token elements (no token matrix in HBM at all)
+          // One quad of the updater's input token (mvtracker.py:379-387): [sin|cos flow embedding 3E | flow 3 | fcorr Fc | ffeats Cf |
+          // track mask, visibility 2] + positional + time embedding.  Every load of the quad is issued before anything is computed: embeddings and coordinates unconditionally, the four
+          // values through a branch-free choice of their source row (as four branchy token_elem calls the ~12 loads of a quad ran
+          // one round trip after the other and this staging was 110 k of the kernel's 148 k cycles).  Same expressions, in the
+          // same order, as token_assemble_kernel: bit-identical (test_in_kernel_token_assembly_bit_identical).
           const int n = (int)(m / p.S), sidx = (int)(m - (long long)n * p.S);
+          const int E = p.t_E, Fc = p.t_Fc, Cf = p.t_Cf, D = p.t_D, d0 = k0 + c;
+          const int o1 = 3 * E + 3, o2 = o1 + Fc, o3 = o2 + Cf;  // first element of fcorr / ffeats / (mask, visibility)
           const float* cc = p.t_coords + m * 3;
           const float* c0 = p.t_coords + (long long)n * p.S * 3;
-          const float fl[3] = {cc[0] - c0[0], cc[1] - c0[1], cc[2] - c0[2]};
-          f32x4 tv;
+          const float* pp = p.t_pos + (long long)n * D;
+          const float* tp = p.t_time + (long long)sidx * D;
+          float pe[4], te[4], sv[4], c6[6];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tv[e] = k0 + c + e < p.t_D ? token_elem(p, m, n, sidx, k0 + c + e, fl) : 0.f;
+          for (int e = 0; e < 3; ++e) {
+            c6[e] = cc[e];
+            c6[3 + e] = c0[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int de = d0 + e < D ? d0 + e : D - 1;
+            pe[e] = pp[de];
+            te[e] = tp[de];
+            const int ds = de < o1 ? o1 : de;  // (flow / embedding elements take their value from fl: any valid address will do)
+            const float* src = ds < o2 ? p.t_fcorr + m * Fc + (ds - o1) : (ds < o3 ? p.t_ffeats + m * Cf + (ds - o2) : p.t_maskvis + m * 2 + (ds - o3));
+            sv[e] = *src;
+          }
+          const float fl[3] = {c6[0] - c6[3], c6[1] - c6[4], c6[2] - c6[5]};
+          f32x4 tv;
+          if (d0 + 3 < 3 * E) {
+            // a quad inside the sin | cos embedding of one axis (E is even, d0 a multiple of 4): elements (0, 1) and (2, 3) are the
+            // sine and cosine of the SAME argument -- one sincosf each
+            const int a = d0 / E, w0 = d0 - a * E;
+            const float step = 1000.0f / (float)E;
+            float sn0, cs0, sn1, cs1;
+            sincosf(fl[a] * ((float)w0 * step), &sn0, &cs0);
+            sincosf(fl[a] * ((float)(w0 + 2) * step), &sn1, &cs1);
+            sv[0] = sn0;
+            sv[1] = cs0;
+            sv[2] = sn1;
+            sv[3] = cs1;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int de = d0 + e;
+              if (de < o1) sv[e] = fl[de - 3 * E < 0 ? 0 : de - 3 * E];  // (the three flow components; never an embedding element here)
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tv[e] = d0 + e < D ? (sv[e] + pe[e]) + te[e] : 0.f;
           w = __builtin_bit_cast(u32x2, __builtin_convertvector(tv, bf16x4));
         }
         *reinterpret_cast<u32x2*>(&As[row * LDT + c]) = w;
       }
+      STAMP(1 + 4 * half);
       __syncthreads();
+      STAMP(2 + 4 * half);
       if (half == 0) gemm_wt<KSA, NMB>(v, p.win + ((long long)wave * (KSA + KSB) * 64 + lane) * 8, &As[r * LDT + 8 * h], LDT, 0);
       else gemm_wt<KSB, NMB>(v, p.win + (((long long)wave * (KSA + KSB) + KSA) * 64 + lane) * 8, &As[r * LDT + 8 * h], LDT, 0);
+      STAMP(3 + 4 * half);
     }
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
