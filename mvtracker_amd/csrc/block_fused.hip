@@ -647,67 +647,79 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     for (int half = 0; half < 2; ++half) {
       const int k0 = half ? KSA * 16 : 0, kq = (half ? KSB : KSA) * 4;  // float4 per row of this half
       if (half) __syncthreads();  // every wave is done with the first half
-      for (int f = t; f < BM * kq; f += NT) {
-        const int row = f / kq, c = (f - row * kq) * 4;
-        const long long m = grow(row);
-        u32x2 w = (u32x2){0u, 0u};
-        if (p.tokx) {
+      if (p.tokx) {
+        for (int f = t; f < BM * kq; f += NT) {
+          const int row = f / kq, c = (f - row * kq) * 4;
+          const long long m = grow(row);
+          u32x2 w = (u32x2){0u, 0u};
           if (m >= 0 && m < p.Mp && k0 + c < p.ldtok)
             w = __builtin_bit_cast(u32x2, __builtin_convertvector(*reinterpret_cast<const f32x4*>(p.tokx + m * (long long)p.ldtok + k0 + c), bf16x4));
-        } else if (m >= 0 && m < p.Mp && k0 + c < p.t_D) {  // assemble the token elements (no token matrix in HBM at all)
-          // One quad of the updater's input token (mvtracker.py:379-387): [sin|cos flow embedding 3E | flow 3 | fcorr Fc | ffeats Cf |
-          // track mask, visibility 2] + positional + time embedding.  Every load of the quad is issued before anything is computed: embeddings and coordinates unconditionally, the four
-          // values through a branch-free choice of their source row (as four branchy token_elem calls the ~12 loads of a quad ran
-          // one round trip after the other and this staging was 110 k of the kernel's 148 k cycles).  Same expressions, in the
-          // same order, as token_assemble_kernel: bit-identical (test_in_kernel_token_assembly_bit_identical).
+          *reinterpret_cast<u32x2*>(&As[row * LDT + c]) = w;
+        }
+      } else {
+        // The token rows are ASSEMBLED here (no token matrix in HBM at all).  One element of the updater's input token
+        // (mvtracker.py:379-387): [sin|cos flow embedding 3E | flow 3 | fcorr Fc | ffeats Cf | track mask, visibility 2] + positional
+        // + time embedding -- the same expressions, in the same order, as token_assemble_kernel: bit-identical
+        // (test_in_kernel_token_assembly_bit_identical).  A wave takes whole rows (8 each), its lanes sweep the row's element PAIRS:
+        // everything per row (track, frame, flow) is wave-uniform, a wave's loads are contiguous along the row, the six loads of
+        // a pair are issued before its arithmetic, and a sin | cos pair shares one sincosf.  (As quads of four branchy per-element
+        // calls -- a dozen dependent, 16-byte-strided 4-byte loads per quad -- this staging was 110 k of the kernel's 148 k cycles:
+        // bound by the NUMBER of scattered load instructions, 2.7 k per workgroup.)
+        const int E = p.t_E, Fc = p.t_Fc, Cf = p.t_Cf, D = p.t_D;
+        const int o1 = 3 * E + 3, o2 = o1 + Fc, o3 = o2 + Cf;  // first element of fcorr / ffeats / (mask, visibility)
+        const int wp = kq * 2;                                  // element pairs per row of this half
+        const float step = 1000.0f / (float)E;
+#pragma unroll 1
+        for (int rr = wave; rr < BM; rr += 8) {
+          const long long mm = grow(rr);
+          const bool okr = mm >= 0 && mm < p.Mp;  // (wave-uniform)
+          const long long m = okr ? mm : 0;
           const int n = (int)(m / p.S), sidx = (int)(m - (long long)n * p.S);
-          const int E = p.t_E, Fc = p.t_Fc, Cf = p.t_Cf, D = p.t_D, d0 = k0 + c;
-          const int o1 = 3 * E + 3, o2 = o1 + Fc, o3 = o2 + Cf;  // first element of fcorr / ffeats / (mask, visibility)
           const float* cc = p.t_coords + m * 3;
           const float* c0 = p.t_coords + (long long)n * p.S * 3;
+          const float fl[3] = {cc[0] - c0[0], cc[1] - c0[1], cc[2] - c0[2]};
           const float* pp = p.t_pos + (long long)n * D;
           const float* tp = p.t_time + (long long)sidx * D;
-          float pe[4], te[4], sv[4], c6[6];
+          const float* fcr = p.t_fcorr + m * Fc - o1;
+          const float* ffr = p.t_ffeats + m * Cf - o2;
+          const float* mvr = p.t_maskvis + m * 2 - o3;
+          constexpr int SW = 3;  // sweeps of 64 pairs cover a half row (152 / 144 pairs)
+          float pe[SW][2], te[SW][2], sv[SW][2];
 #pragma unroll
-          for (int e = 0; e < 3; ++e) {
-            c6[e] = cc[e];
-            c6[3 + e] = c0[e];
-          }
+          for (int u = 0; u < SW; ++u) {
+            const int d0 = k0 + 2 * (lane + 64 * u);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int de = d0 + e < D ? d0 + e : D - 1;
-            pe[e] = pp[de];
-            te[e] = tp[de];
-            const int ds = de < o1 ? o1 : de;  // (flow / embedding elements take their value from fl: any valid address will do)
-            const float* src = ds < o2 ? p.t_fcorr + m * Fc + (ds - o1) : (ds < o3 ? p.t_ffeats + m * Cf + (ds - o2) : p.t_maskvis + m * 2 + (ds - o3));
-            sv[e] = *src;
-          }
-          const float fl[3] = {c6[0] - c6[3], c6[1] - c6[4], c6[2] - c6[5]};
-          f32x4 tv;
-          if (d0 + 3 < 3 * E) {
-            // a quad inside the sin | cos embedding of one axis (E is even, d0 a multiple of 4): elements (0, 1) and (2, 3) are the
-            // sine and cosine of the SAME argument -- one sincosf each
-            const int a = d0 / E, w0 = d0 - a * E;
-            const float step = 1000.0f / (float)E;
-            float sn0, cs0, sn1, cs1;
-            sincosf(fl[a] * ((float)w0 * step), &sn0, &cs0);
-            sincosf(fl[a] * ((float)(w0 + 2) * step), &sn1, &cs1);
-            sv[0] = sn0;
-            sv[1] = cs0;
-            sv[2] = sn1;
-            sv[3] = cs1;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int de = d0 + e;
-              if (de < o1) sv[e] = fl[de - 3 * E < 0 ? 0 : de - 3 * E];  // (the three flow components; never an embedding element here)
+            for (int e = 0; e < 2; ++e) {
+              const int de = d0 + e < D ? d0 + e : D - 1;
+              pe[u][e] = pp[de];
+              te[u][e] = tp[de];
+              const int ds = de < o1 ? o1 : de;  // (flow / embedding elements take their value from fl: any valid address will do)
+              const float* src = ds < o2 ? fcr + ds : (ds < o3 ? ffr + ds : mvr + ds);
+              sv[u][e] = *src;
             }
           }
+          __builtin_amdgcn_sched_barrier(0);  // (every load of the row ahead of the first sincos)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tv[e] = d0 + e < D ? (sv[e] + pe[e]) + te[e] : 0.f;
-          w = __builtin_bit_cast(u32x2, __builtin_convertvector(tv, bf16x4));
+          for (int u = 0; u < SW; ++u) {
+            const int j = lane + 64 * u, d0 = k0 + 2 * j;
+            if (j >= wp) continue;
+            unsigned w = 0u;
+            if (okr && d0 < D) {
+              if (d0 + 1 < 3 * E) {  // sine and cosine of one argument (d0 and E are even)
+                const int a = (d0 >= E) + (d0 >= 2 * E), w0 = d0 - a * E;
+                sincosf(fl[a] * ((float)w0 * step), &sv[u][0], &sv[u][1]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                  if (d0 + e < o1) sv[u][e] = fl[d0 + e - 3 * E];  // (the three flow components)
+              }
+              const float v0 = (sv[u][0] + pe[u][0]) + te[u][0];
+              const float v1 = d0 + 1 < D ? (sv[u][1] + pe[u][1]) + te[u][1] : 0.f;
+              w = (unsigned)mvt_bf16_bits(v0) | ((unsigned)mvt_bf16_bits(v1) << 16);
+            }
+            *reinterpret_cast<unsigned*>(&As[rr * LDT + 2 * j]) = w;
+          }
         }
-        *reinterpret_cast<u32x2*>(&As[row * LDT + c]) = w;
       }
       STAMP(1 + 4 * half);
       __syncthreads();
