@@ -172,6 +172,8 @@ __device__ __forceinline__ void gemm_wt(f32x16 (&acc)[NMB], const unsigned short
   }
 }
 
+// (MVT_ABL_NOLOAD / NOLDS / NOMFMA / NOGELU: ablation builds -- a phase compiled out to see what it costs, tools/time_block.py;
+//  never defined in the shipped library.)
 // Same product with a persistent weight-fragment queue: wq holds the first PFQ fragments of this stream on entry and the
 // first PFQ fragments of the NEXT stream (nxt -> its row, 8h already applied) on exit, so the global-load latency of
 // every GEMM call hides under the previous call instead of being exposed at its start.  KS % PFQ == 0.
