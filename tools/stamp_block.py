@@ -19,7 +19,7 @@ dev = "cuda"
 kind = sys.argv[1] if len(sys.argv) > 1 else "plain"   # plain | time | p2v
 n_tracks, S = 1024, 12
 C, H, Ko = 256, 1024, 288
-lib = ctypes.CDLL(os.environ["MVT_LIB"]) if os.environ.get("MVT_LIB") else None
+lib = ctypes.CDLL(os.environ["MVT_LIB"]) if (os.environ.get("MVT_LIB") and not os.environ.get("TIME_ONLY")) else None  # TIME_ONLY=1: time another build
 
 
 def mk(n, k):
