@@ -1,0 +1,46 @@
+"""First divergence between the product (fp32 mode) and the oracle on a multi-window clip: per window and iteration, the kNN
+index sets, correlation features, deltas.  python tools/diag_multiwindow.py [S] [seed]"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvtracker_amd import synth
+from mvtracker_amd.tracker import MVTracker
+from oracle import mvt_oracle as O
+DEV = "cuda:0"
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 41 + S
+cfg = O.TrackerConfig(sliding_window_len=S)
+m = MVTracker(hidden_size=256, sliding_window_len=S).eval()
+sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+m = m.to(DEV)
+W = O.make_weights(cfg, seed=0)
+T = lambda a: torch.from_numpy(np.asarray(a))
+clip = synth.make_clip(seed, V=2, T=2 * S + S // 2, H=96, W=128, N=21)
+a = [T(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
+otr = {}
+ro = O.tracker_forward(W, cfg, *a, iters=3, knn_mode="exact", trace=otr)
+tr = []
+r = m(*[t.to(DEV) for t in a], iters=3, trace=tr)
+torch.cuda.synchronize()
+L = 4
+for w, (pw, ow) in enumerate(zip(tr, otr["windows"])):
+    for it in range(3):
+        pidx = pw["knn_idx"][it].cpu().long()            # (L, n, S, K)
+        n = pidx.shape[1]
+        for l in range(L):
+            oidx = ow["knn_idx"][it * L + l].permute(1, 0, 2)  # (n, S, K)
+            neq = (pidx[l] != oidx[:n]).any(-1)
+            if neq.any():
+                bad = neq.nonzero()
+                print(f"window {w} iter {it} level {l}: {int(neq.sum())} of {neq.numel()} (track, frame) neighbour sets differ; first {bad[0].tolist()}")
+                tq, fq = bad[0].tolist()
+                print("   product", pidx[l, tq, fq].tolist())
+                print("   oracle ", oidx[tq, fq].tolist())
+        fc_o = ow["fcorrs"][it][0].permute(1, 0, 2)
+        d = (pw["fcorrs"][it].cpu() - fc_o[:n]).abs().max().item()
+        de = (pw["delta"][it].cpu() - ow["delta"][it][:, :n]).abs().max().item() if pw["delta"][it].dim() == ow["delta"][it].dim() else float("nan")
+        print(f"window {w} iter {it}: fcorr max abs diff {d:.2e}, delta max abs diff {de:.2e}")
