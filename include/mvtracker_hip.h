@@ -45,10 +45,6 @@ extern "C" {
 /* library / device introspection (host) */
 int mvt_abi_version(void);
 const char* mvt_build_arch(void); /* "gfx950" */
-/* host helpers (not on the data path): a HIP stream restricted to the compute units whose bit is set in mask (n_words x 32 bits,
- * hipExtStreamCreateWithCUMask) -- the tracker's second (encoder) stream; returns a hipStream_t as void*, NULL on failure */
-void* mvt_stream_create_cu_mask(const unsigned* mask, int n_words);
-int mvt_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense GEMM on the matrix cores (fp32 MFMA 32x32x2, exact fp32 FMA chains).
@@ -103,8 +99,6 @@ int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const uns
  *                   in out_partial are taken before the rounding) */
 #define MVT_IO_IN_BF16 1
 #define MVT_IO_OUT_BF16 2
-#define MVT_IO_BACKGROUND 16 /* mvt_conv2d_bf16: launch at reduced occupancy (one workgroup per CU): work on a second stream
-                                that should leave the chip's CUs mostly to the caller's main stream */
 int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad, int split /* wt_lo != NULL */);
 int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
                     void* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
@@ -395,10 +389,6 @@ int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, c
                        float* workspace /* NULL, or 4 * groups*heads*ceil(nq/64) * 4352 floats: lets a long-key attention
                                            with few (group, head) chunks cut its keys over 4 workgroups per chunk */,
                        void* stream);
-/* io_flags bit of mvt_attention_bf16: the key-split partials are combined by the LAST workgroup of every chunk to publish its
- * partial (fixed combination order: deterministic) instead of by a second launch.  The workspace then carries a tail of
- * groups*heads*ceil(nq/64) uint32 ticket counters after the partials; they must be ZERO on entry and are left zero. */
-#define MVT_ATTN_FUSED_MERGE 4
 /* io_flags bit: stop after the key-split partials (no merge launch, `o` is not written); the consumer combines them
  * (mvt_attn_block_fused_bf16, MVT_ATTN_PARTIALS).  Only valid when the key-split path is taken (nk >= 512, < 256 chunks). */
 #define MVT_ATTN_PARTIALS_ONLY 8
@@ -463,9 +453,8 @@ typedef struct mvt_updater_block {
 typedef struct mvt_updater_weights {
   int depth, hidden, heads, dim_head, n_virtual, S, token_dim, out_dim;
   int fuse_attention; /* bit 0: time attention, bit 1: point<-virtual, bit 2: virtual self attention run inside the block kernels
-                         (mvt_attn_block_fused_bf16) instead of as separate launches; bit 3: the key-split virtual<-point attention
-                         merges its partials itself (MVT_ATTN_FUSED_MERGE); bit 4: the virtual<-point block combines the partials
-                         (MVT_ATTN_PARTIALS, no merge launch); results are bit-identical either way */
+                         (mvt_attn_block_fused_bf16) instead of as separate launches; bit 3: unused (ignored); bit 4: the virtual<-point block
+                         combines the key-split partials (MVT_ATTN_PARTIALS, no merge launch); results are bit-identical either way */
   const float* virtual_tokens; /* [n_virtual][hidden] */
   mvt_lin_rows input_transform, flow0, flow2, flow4;
   mvt_updater_block time_blk[MVT_UPDATER_MAX_DEPTH], v2p[MVT_UPDATER_MAX_DEPTH], vself[MVT_UPDATER_MAX_DEPTH], p2v[MVT_UPDATER_MAX_DEPTH];
@@ -488,7 +477,7 @@ int mvt_updateformer_forward(const mvt_updater_weights* w /* host struct of devi
  * bf16 mode with bf16 activations.  conv[i]: row-major bf16 weights [Cout][ldw] with rows (kh, kw, cin) as mvt_conv2d_bf16 takes them
  * (the 7x7 stem as [64][7][8][4]) + fp32 bias, in the order: 0 conv1; for layer l = 1..4: 1 + 5(l-1) + {0 .0.conv1, 1 .0.conv2,
  * 2 .0.downsample.0 (unused for l = 1), 3 .1.conv1, 4 .1.conv2}; 21 conv2; 22 conv3.  workspace: mvt_encoder_workspace_bytes bytes,
- * 256-B aligned, no state between calls.  background: launch the convolutions at reduced occupancy (MVT_IO_BACKGROUND). */
+ * 256-B aligned, no state between calls. */
 #define MVT_ENCODER_CONVS 23
 typedef struct mvt_conv_weights {
   const unsigned short* w;
@@ -500,7 +489,7 @@ typedef struct mvt_encoder_weights {
 } mvt_encoder_weights;
 long long mvt_encoder_workspace_bytes(int n, int H, int W, int latent_dim); /* host; -1 on bad arguments */
 int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4, int n, int H, int W, void* out_rows, int ldo, int out_bf16,
-                        void* workspace, long long workspace_bytes, int background, void* stream);
+                        void* workspace, long long workspace_bytes, void* stream);
 
 /* mvt_updateformer_forward with the 581-wide token rows ASSEMBLED inside its first kernel (mvt_token_input_proj_bf16: the
  * arithmetic of mvt_token_assemble) instead of read from a token matrix: one refinement iteration after the correlation is then

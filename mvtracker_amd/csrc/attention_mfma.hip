@@ -41,7 +41,7 @@ template <int KS, bool BFIN>
 __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel(
     const float* __restrict__ q, int ldq, long long q_gs, long long q_is, const float* __restrict__ k, const float* __restrict__ v,
     int ldkv, long long k_gs, long long k_is, float* __restrict__ o, int ldo, int groups, int nq, int nk, int heads, int bf_in_unused,
-    int bf_out, float* __restrict__ ws, unsigned* __restrict__ tickets) {
+    int bf_out, float* __restrict__ ws) {
   constexpr int bf_in = BFIN ? 1 : 0;
   // ws != null: the keys are additionally cut over gridDim.y workgroups; wave 0 leaves its (m, l, O) partial in ws and
   // attention_merge_kernel finishes the softmax (the 64 virtual x 1024 point attention is only 72 (frame, head) chunks)
@@ -275,60 +275,7 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
             *reinterpret_cast<f32x4*>(ws + mvt_part_off(rec, 1 + (mb * 2 + db) * 4 + gq, lane)) =
                 (f32x4){oacc[mb][db][4 * gq], oacc[mb][db][4 * gq + 1], oacc[mb][db][4 * gq + 2], oacc[mb][db][4 * gq + 3]};
     }
-    if (!tickets) return;  // attention_merge_kernel finishes
-    // Merge without a second launch: the workgroup that publishes its partial LAST (ticket counter per chunk) combines the
-    // gridDim.y partials -- always in the fixed order 0, 1, 2, ..., so the result does not depend on who arrives last -- and
-    // writes the output.  Release before the ticket (the partial is visible device-wide), acquire after it.
-    __threadfence();
-    unsigned tk = 0;
-    if (lane == 0) tk = atomicAdd(&tickets[chunk_id], 1u);
-    tk = __builtin_amdgcn_readfirstlane(tk);
-    if (tk + 1 != gridDim.y) return;
-    __threadfence();
-    if (lane == 0) tickets[chunk_id] = 0u;  // left zero for the next launch
-    auto ntl = [&](long long rec, int quad) {
-      const float* q = ws + mvt_part_off(rec, quad, lane);
-      return (f32x4){__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2),
-                     __builtin_nontemporal_load(q + 3)};
-    };
-    {
-      const f32x4 q0 = ntl(chunk_id, 0);
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        m[mb] = q0[mb];
-        l[mb] = q0[2 + mb];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 t = ntl(chunk_id, 1 + (mb * 2 + db) * 4 + gq);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) oacc[mb][db][4 * gq + e] = t[e];
-          }
-      }
-    }
-#pragma unroll 1
-    for (int w = 1; w < (int)gridDim.y; ++w) {
-      const long long rec = w * nchunk + chunk_id;
-      const f32x4 q0 = ntl(rec, 0);
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        const float mw = q0[mb];
-        const float mn = fmaxf(m[mb], mw);
-        const float ca = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
-        const float cb = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
-        l[mb] = fmaf(l[mb], ca, q0[2 + mb] * cb);
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 t = ntl(rec, 1 + (mb * 2 + db) * 4 + gq);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) oacc[mb][db][4 * gq + e] = fmaf(oacc[mb][db][4 * gq + e], ca, t[e] * cb);
-          }
-        m[mb] = mn;
-      }
-    }
+    return;  // attention_merge_kernel, or the prologue of the consuming block kernel (MVT_ATTN_PARTIALS), finishes the softmax
   }
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
@@ -434,35 +381,33 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* __res
 extern "C" int mvt_attention_bf16(const void* q, int ldq, long long q_gs, long long q_is, const void* k, const void* v,
                                   int ldkv, long long k_gs, long long k_is, void* o, int ldo, int groups, int nq, int nk,
                                   int heads, int dh, int io_flags, float* workspace, void* stream) {
-  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16 | MVT_ATTN_FUSED_MERGE | MVT_ATTN_PARTIALS_ONLY)) == 0);
+  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16 | MVT_ATTN_PARTIALS_ONLY)) == 0);
   const bool partials_only = (io_flags & MVT_ATTN_PARTIALS_ONLY) != 0;
   const int bf_in = io_flags & MVT_IO_IN_BF16 ? 1 : 0, bf_out = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
-  const bool fused_merge = (io_flags & MVT_ATTN_FUSED_MERGE) != 0;
   MVT_REQUIRE(!bf_in || (ldq % 8 == 0 && ldkv % 8 == 0));  // 16-B aligned rows
   MVT_REQUIRE(!bf_out || ldo % 8 == 0);
   MVT_REQUIRE(q && k && v && o && groups > 0 && nq > 0 && nk > 0 && heads > 0 && dh == DH);
   MVT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= heads * dh && ldkv >= heads * dh && ldo >= heads * dh);
   MVT_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 16 == 0));
   const long long nchunk = (long long)groups * heads * ((nq + 63) / 64);
-#define LAUNCH_T(KS, BF, BLOCKS, THREADS, WSP, TK)                                                                                    \
+#define LAUNCH_T(KS, BF, BLOCKS, THREADS, WSP)                                                                                        \
   hipLaunchKernelGGL((attention_mfma_kernel<KS, BF>), BLOCKS, dim3(THREADS), 0, mvt_stream(stream), (const float*)q, ldq, q_gs, q_is, \
-                     (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out, WSP, TK)
+                     (const float*)k, (const float*)v, ldkv, k_gs, k_is, (float*)o, ldo, groups, nq, nk, heads, bf_in, bf_out, WSP)
 #define LAUNCH(KS, BLOCKS, THREADS)                                         \
   do {                                                                      \
-    if (bf_in) LAUNCH_T(KS, true, dim3((unsigned)(BLOCKS)), THREADS, WS, nullptr);  \
-    else LAUNCH_T(KS, false, dim3((unsigned)(BLOCKS)), THREADS, WS, nullptr);       \
+    if (bf_in) LAUNCH_T(KS, true, dim3((unsigned)(BLOCKS)), THREADS, WS);  \
+    else LAUNCH_T(KS, false, dim3((unsigned)(BLOCKS)), THREADS, WS);       \
   } while (0)
   constexpr int NSPLIT = MVT_ATTN_NSPLIT;
-  MVT_REQUIRE(!partials_only || (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0 && !fused_merge));
+  MVT_REQUIRE(!partials_only || (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0));
   if (nk >= 512 && nchunk < 256 && workspace && ((nk + 31) / 32) % NSPLIT == 0) {
     // too few (group, head) chunks to fill the chip: cut the keys over NSPLIT workgroups per chunk as well
     MVT_REQUIRE((uintptr_t)workspace % 16 == 0);
 #define WS workspace
-    unsigned* tickets = fused_merge ? reinterpret_cast<unsigned*>(workspace + (long long)NSPLIT * nchunk * 64 * 68) : nullptr;
-    if (bf_in) LAUNCH_T(4, true, dim3((unsigned)nchunk, NSPLIT), 256, workspace, tickets);
-    else LAUNCH_T(4, false, dim3((unsigned)nchunk, NSPLIT), 256, workspace, tickets);
+    if (bf_in) LAUNCH_T(4, true, dim3((unsigned)nchunk, NSPLIT), 256, workspace);
+    else LAUNCH_T(4, false, dim3((unsigned)nchunk, NSPLIT), 256, workspace);
 #undef WS
-    if (!fused_merge && !partials_only)
+    if (!partials_only)
       hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)mvt_cdiv(nchunk, 4)), dim3(256), 0, mvt_stream(stream), workspace, NSPLIT,
                          nchunk, q_gs, q_is, (float*)o, ldo, nq, heads, bf_out);
     return mvt_launch_status();

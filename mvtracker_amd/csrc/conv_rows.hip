@@ -631,10 +631,8 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
   a.slots = mvt_detail_conv_rows_slots(Ho, Wo, mvt_detail_conv_rows_tile_rows(ksize, stride, Ho));
   a.in_bf16 = io_flags & MVT_IO_IN_BF16 ? 1 : 0;
   a.out_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
-  // background launch (the encoder of later frames on the second stream): an unused dynamic LDS request caps the kernel at one
-  // workgroup per CU instead of three, so that the updater's kernels on the main stream keep most of every CU
-  static const int bg_bytes = getenv("MVT_BG_LDS") ? atoi(getenv("MVT_BG_LDS")) : 60 * 1024;
-  const unsigned bg_lds = (io_flags & MVT_IO_BACKGROUND) ? (unsigned)bg_bytes : 0u;
+  // (no dynamic LDS anywhere in this library: every kernel's group segment is its static size, checked at compile time against
+  //  the 160 KiB a workgroup may own -- see DESIGN.md section 5, "a queue abort worth remembering")
   const bool n96 = Cout % 64 != 0 && Cout % 96 == 0;
   const int bn = n96 ? 96 : 64;
   // (64-channel tiles keep three workgroups per CU with bf16 tensors: measured 1.4x faster than 128-channel tiles at one per CU)
@@ -643,8 +641,8 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
 #define LAUNCH2(TM_, TN_, KS_, S_, NW_, INB_)                                                                                       \
   do {                                                                                                                             \
     constexpr bool fits = NW_ * stage_elems<TN_>() <= Geo<TM_, KS_, S_, NW_>::NSLOT * LDP;                                          \
-    if (fits && st_ok) hipLaunchKernelGGL((conv_rows_bf16<TM_, TN_, KS_, S_, INB_, NW_, fits>), grid, dim3(64 * NW_), bg_lds, stream, a); \
-    else hipLaunchKernelGGL((conv_rows_bf16<TM_, TN_, KS_, S_, INB_, NW_, false>), grid, dim3(64 * NW_), bg_lds, stream, a);            \
+    if (fits && st_ok) hipLaunchKernelGGL((conv_rows_bf16<TM_, TN_, KS_, S_, INB_, NW_, fits>), grid, dim3(64 * NW_), 0, stream, a); \
+    else hipLaunchKernelGGL((conv_rows_bf16<TM_, TN_, KS_, S_, INB_, NW_, false>), grid, dim3(64 * NW_), 0, stream, a);            \
   } while (0)
 #define LAUNCH(TM_, KS_, S_, NW_)                                                                                                   \
   do {                                                                                                                             \

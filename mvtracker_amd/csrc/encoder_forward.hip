@@ -58,7 +58,7 @@ extern "C" long long mvt_encoder_workspace_bytes(int n, int H, int W, int C) {
   } while (0)
 
 extern "C" int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4, int n, int H, int W, void* out_rows, int ldo,
-                                   int out_bf16, void* workspace, long long workspace_bytes, int background, void* stream) {
+                                   int out_bf16, void* workspace, long long workspace_bytes, void* stream) {
   MVT_REQUIRE(w && x4 && out_rows && workspace && n > 0 && H >= 16 && W >= 16 && H % 4 == 0 && W % 4 == 0);
   const int C = w->latent_dim;
   MVT_REQUIRE(C > 0 && C % 32 == 0 && ldo >= C && (out_bf16 == 0 || out_bf16 == 1));
@@ -71,7 +71,7 @@ extern "C" int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4
   const long long st_stride = (long long)n * 256 * 2;
   int st_next = 0;
   auto new_st = [&]() { float* s = stb + (st_next % 8) * st_stride; ++st_next; return s; };
-  const int BF = MVT_IO_IN_BF16 | MVT_IO_OUT_BF16, bg = background ? MVT_IO_BACKGROUND : 0;
+  const int BF = MVT_IO_IN_BF16 | MVT_IO_OUT_BF16;
 
   // one convolution + the (mean, rstd) of its output
   auto conv = [&](int ci, const void* in, int io_in, void* out, int hh, int ww, int cin, int cout, int k, int stride, int pad, int ld_out,
@@ -85,7 +85,7 @@ extern "C" int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4
       MVT_REQUIRE(slots > 0);
       pp = part;
     }
-    ENC_TRY(mvt_conv2d_bf16(in, cw.w, nullptr, cw.b, out, n, hh, ww, cin, cout, k, k, stride, pad, ld_out, MVT_ACT_NONE, io_in | io_out | bg,
+    ENC_TRY(mvt_conv2d_bf16(in, cw.w, nullptr, cw.b, out, n, hh, ww, cin, cout, k, k, stride, pad, ld_out, MVT_ACT_NONE, io_in | io_out,
                             in_stats, pp, stream));
     if (st_out) {
       *st_out = new_st();

@@ -881,8 +881,6 @@ extern "C" int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, cons
   a.out_part = out_partial;
   a.a_bf16 = io_flags & MVT_IO_IN_BF16 ? 1 : 0;
   a.c_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
-  const int background = io_flags & MVT_IO_BACKGROUND;
-  io_flags &= ~MVT_IO_BACKGROUND;
   MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16)) == 0 && (!io_flags || !wt_lo));  // bf16 tensors: bf16 mode only
   MVT_REQUIRE(!a.a_bf16 || (Cin % 32 == 0 && (uintptr_t)in % 8 == 0));                          // (the stem reads fp32 RGB)
   a.slots = mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, wt_lo != nullptr);
@@ -890,7 +888,7 @@ extern "C" int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, cons
   if (!wt_lo && Cin == 4 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout <= 64 && act == MVT_ACT_NONE)
     return mvt_detail_stem7x7_rows((const float*)in, wt_hi, a.ldw, bias, out, n, H, W, Cout, ldo, io_flags, out_partial, mvt_stream(stream));
   if (rows)
-    return mvt_detail_conv_rows(in, wt_hi, a.ldw, bias, out, n, H, W, Cin, Cout, KH, stride, ldo, io_flags | background, in_stats, out_partial,
+    return mvt_detail_conv_rows(in, wt_hi, a.ldw, bias, out, n, H, W, Cin, Cout, KH, stride, ldo, io_flags, in_stats, out_partial,
                                 mvt_stream(stream));
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % CK == 0 && (long long)n * mvt_cdiv(Ho, HT) * mvt_cdiv(Wo, HW_) * 4 < (1LL << 31))
     return wt_lo ? launch_conv3x3_halo<true>(a, n, mvt_stream(stream)) : launch_conv3x3_halo<false>(a, n, mvt_stream(stream));

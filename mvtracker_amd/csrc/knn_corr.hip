@@ -290,7 +290,8 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
   // Coarse level (single segment, <= 64 groups of 64 tiles): one group box per lane, same bound arithmetic -- a group box contains
   // its tiles' boxes, so its bound is <= theirs and a culled group cannot hold a survivor either.
   unsigned long long gmask = ~0ULL;
-  if (gbox && fbox && nseg == 1 && ntiles > 64 && ntiles <= 64 * 64) {
+  const bool use_groups = gbox && fbox && nseg == 1 && ntiles > 64 && ntiles <= 64 * 64;
+  if (use_groups) {
     const int ng = (ntiles + 63) >> 6;
     bool near = false;
     if (lane < ng) {
@@ -309,7 +310,7 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
   }
 
   for (int tb = t0; tb < t1; tb += 64) {
-    if (!((gmask >> (tb >> 6)) & 1ULL)) continue;  // (t0 = 0 whenever the mask is in use)
+    if (use_groups && !((gmask >> (tb >> 6)) & 1ULL)) continue;  // (t0 = 0 and tb < 4096 whenever the mask is in use: the shift stays below 64)
     // which of the next 64 tiles can hold a point within thr of any of the Q queries?  One tile per lane.  The bound
     // uses the distance arithmetic of the scan itself on the per-axis gaps to the box, and every rounding step is
     // monotonic, so bound <= d2 of every point in the box in floating point: a culled tile cannot hold a survivor.

@@ -30,8 +30,7 @@ inline Layout layout(long long n, long long S) {
   L.qp = take(Mp * INNER * 2);
   L.att = take(M * INNER * 2);
   L.split_ws = take((MLP / 256 + 1) * Mv * H_ * 4);
-  L.attn_ws = take(4LL * S * HEADS * 1 * 64 * 68 * 4 + (long long)S * HEADS * 4);  // key-split partials of the 64-query
-                                                                                    // virtual<-point attention + ticket counters
+  L.attn_ws = take(4LL * S * HEADS * 1 * 64 * 68 * 4);  // key-split partials of the 64-query virtual<-point attention
   L.ldh = (OUT + 3) / 4 * 4;
   L.h1 = take(Mp * L.ldh * 4);
   L.h2 = take(Mp * L.ldh * 4);
@@ -117,8 +116,6 @@ static int updater_run(const mvt_updater_weights* w, const float* x, int ldx, co
   };
   const bool fuse_time = (w->fuse_attention & 1) && S <= 32, fuse_p2v = (w->fuse_attention & 2) != 0, fuse_vs = (w->fuse_attention & 4) != 0;
 
-  // ticket counters of the fused attention merge: zero on entry of the first use, left zero by every launch
-  if (hipMemsetAsync(attn_ws + 4LL * S * HEADS * 64 * 68, 0, (size_t)S * HEADS * 4, mvt_stream(stream)) != hipSuccess) return MVT_ERR_HIP_BASE;
   // tokens: input transform of the point rows, learned virtual tokens repeated over the S frames (blocks.py:456-459), and the
   // first time-attention q|k|v projection -- one launch when the fragment-major input weights are available
   {
@@ -160,7 +157,7 @@ static int updater_run(const mvt_updater_weights* w, const float* x, int ldx, co
     // the key-split path of mvt_attention_bf16 needs >= 512 keys in 4 x whole 32-key blocks; otherwise the plain form
     const bool parts = (w->fuse_attention & 16) && n >= 512 && ((n + 31) / 32) % MVT_ATTN_NSPLIT == 0;
     MVT_TRY(mvt_attention_bf16(qv, ld3, 1, S, qkv + INNER, qkv + 2 * INNER, ld3, 1, S, av, INNER, S, NV, n, HEADS, DH_,
-                               BF | (parts ? MVT_ATTN_PARTIALS_ONLY : ((w->fuse_attention & 8) ? MVT_ATTN_FUSED_MERGE : 0)), attn_ws, stream));
+                               BF | (parts ? MVT_ATTN_PARTIALS_ONLY : 0), attn_ws, stream));
     {
       const mvt_block_next nx = next_of(vs.qkv, qv, ld3, 0, 0);
       if (parts) {

@@ -29,8 +29,6 @@ P, I, LL, F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 SIGNATURES = {
     "mvt_abi_version": [],
     "mvt_build_arch": [],
-    "mvt_stream_create_cu_mask": [P, I],
-    "mvt_stream_destroy": [P],
     "mvt_gemm": [P, I, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_conv2d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "mvt_split_bf16": [P, P, P, LL, P],
@@ -81,14 +79,14 @@ SIGNATURES = {
     "mvt_window_store": [P, P, P, I, I, I, I, I, P, P, P, P],
     "mvt_track_metrics": [P, P, P, P, P, I, I, I, P, I, F, P, I, P],
     "mvt_encoder_workspace_bytes": [I, I, I, I],
-    "mvt_encoder_forward": [P, P, I, I, I, P, I, I, P, LL, I, P],
+    "mvt_encoder_forward": [P, P, I, I, I, P, I, I, P, LL, P],
     "mvt_updateformer_workspace_bytes": [I, I],
     "mvt_updateformer_forward": [P, P, I, I, P, I, P, P, P, P, LL, P],
     "mvt_updateformer_forward_tokens": [P, P, I, P, I, P, P, P, P, LL, P],
     "mvt_token_input_proj_bf16": [P, P, I, P, I, P, P, P, I, I, I, P, P, P, P, I, P, I, LL, I, P],
     "mvt_update_head_bf16": [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, I, LL, I, I, P, P],
 }
-_RET = {"mvt_build_arch": C.c_char_p, "mvt_stream_create_cu_mask": C.c_void_p, "mvt_encoder_workspace_bytes": C.c_longlong, "mvt_updateformer_workspace_bytes": C.c_longlong}
+_RET = {"mvt_build_arch": C.c_char_p, "mvt_encoder_workspace_bytes": C.c_longlong, "mvt_updateformer_workspace_bytes": C.c_longlong}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(_lib, _name)  # AttributeError here = header / library mismatch
@@ -177,25 +175,6 @@ def _f32c(t):
     return t
 
 
-def create_masked_stream(dev, n_cus: int, spread: bool = False, total: int = 256):
-    """A torch stream on ``dev`` restricted to ``n_cus`` of the ``total`` compute units (hipExtStreamCreateWithCUMask), or None when
-    the runtime refuses.  ``spread``: enabled bits spread evenly over the mask instead of the lowest n bits."""
-    bits = [0] * total
-    if spread:
-        for i in range(n_cus):
-            bits[(i * total) // n_cus] = 1
-    else:
-        for i in range(n_cus):
-            bits[i] = 1
-    words = [sum(bits[32 * w + b] << b for b in range(32)) for w in range(total // 32)]
-    arr = (C.c_uint * len(words))(*words)
-    with torch.cuda.device(dev):
-        ptr = _lib.mvt_stream_create_cu_mask(arr, len(words))
-    if not ptr:
-        return None
-    return torch.cuda.ExternalStream(ptr, device=dev)
-
-
 def abi_version() -> int:
     return _lib.mvt_abi_version()
 
@@ -227,13 +206,10 @@ def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False) -> int:
     return _lib.mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, int(split))
 
 
-IO_BACKGROUND = 16
-
-
 def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE, in_stats=None,
-                out_partial=None, background=False):
+                out_partial=None):
     _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
-          ldo, act, _io(x, out) | (IO_BACKGROUND if background else 0), _ptr(in_stats), _ptr(out_partial), _stream())
+          ldo, act, _io(x, out), _ptr(in_stats), _ptr(out_partial), _stream())
 
 
 def instnorm_finish_slots(partial, slots, mean_rstd, n, HW, Cc):
@@ -615,7 +591,7 @@ def encoder_workspace_bytes(n, H, W, Cc) -> int:
     return int(_lib.mvt_encoder_workspace_bytes(n, H, W, Cc))
 
 
-def encoder_forward(weights: EncoderWeights, x4, n, H, W, out_rows, ldo, workspace, background=False):
+def encoder_forward(weights: EncoderWeights, x4, n, H, W, out_rows, ldo, workspace):
     """BasicEncoder.forward as one library call (bf16 mode): x4 (n,H,W,4) fp32 -> out_rows (n,H/4,W/4,ldo) fp32 or bf16."""
     _call("mvt_encoder_forward", C.addressof(weights), _ptr(_f32c(x4)), n, H, W, _ptr(out_rows), ldo,
-          1 if out_rows.dtype == torch.bfloat16 else 0, _ptr(workspace), workspace.numel(), 1 if background else 0, _stream())
+          1 if out_rows.dtype == torch.bfloat16 else 0, _ptr(workspace), workspace.numel(), _stream())

@@ -119,17 +119,12 @@ class MVTracker(nn.Module):
         self.mfma_attention = True
         self.overlap_encoder = os.environ.get("MVT_OVERLAP", "1") != "0"  # encode later frames on a second stream
         self._side = {}
-        self._background = False
-        self.background_encoder = os.environ.get("MVT_BG_ENCODER", "0") != "0"  # side-stream convs at one workgroup per CU
-        self.side_stream_cus = "0"
         self._scratch = {}
         self.bf16_tokens = os.environ.get("MVT_BF16_TOK", "1") != "0"  # bf16 mode: q/k/v and attention outputs stored as bf16
         self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
         self.bf16_store = os.environ.get("MVT_BF16_STORE", "1") != "0"  # bf16 mode: bf16 feature rows in the frame store
-        # attention inside the block kernels: bit 0 time, bit 1 point<-virtual, bit 2 virtual self; bit 3: in-kernel merge of the
-        # key-split virtual<-point attention -- measured 0.8 ms / step SLOWER than the merge launch (release / acquire fences on the
-        # critical path), so off by default; bit 4: the virtual<-point block combines the key-split partials in its prologue, no merge
-        # launch (all variants are bit-identical to the separate launches)
+        # attention inside the block kernels: bit 0 time, bit 1 point<-virtual, bit 2 virtual self; bit 4: the virtual<-point block
+        # combines the key-split partials in its prologue, no merge launch (all variants are bit-identical to the separate launches)
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
         self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
@@ -226,7 +221,11 @@ class MVTracker(nn.Module):
     # ------------------------------------------------------------------ weight packing for the kernels
     def _signature(self, dev):
         assert self.precision in ("fp32", "bf16x3", "bf16"), self.precision
-        return (str(dev), self.precision, self.fuse_attention, self.fuse_input, self.composite_encoder) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        # (everything _pack reads: the switches that decide which structs / layouts are built, then the parameter versions)
+        flags = (str(dev), self.precision, self.fuse_attention, self.fuse_input, self.composite_encoder, self._composite_updater_ok(),
+                 self._composite_encoder_ok(), self.bf16_tokens, self.bf16_activations, self.fuse_blocks, self.mfma_attention, self.fuse_norm,
+                 self.depth, self.hidden)
+        return flags + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
     def _pack(self, dev) -> dict:
         sig = self._signature(dev)
@@ -400,8 +399,7 @@ class MVTracker(nn.Module):
         if isinstance(wt, tuple):
             slots = hip.conv2d_stat_slots(H, W, cin, k, k, stride, pad, wt[1] is not None) if (stats and self.fuse_norm) else 0
             part = torch.empty(n * slots * cout * 2, device=x.device) if slots else None
-            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo, in_stats=in_stats, out_partial=part,
-                            background=self._background)
+            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo, in_stats=in_stats, out_partial=part)
             if slots:
                 st = torch.empty(n, cout, 2, device=x.device)
                 hip.instnorm_finish_slots(part, slots, st, n, Ho * Wo, cout)
@@ -453,7 +451,7 @@ class MVTracker(nn.Module):
         C = self.latent_dim
         if "encoder_struct" in pk and out_rows.is_contiguous():  # the whole CNN as ONE library call (mvt_encoder_forward)
             ws = self._workspace(hip.encoder_workspace_bytes(n, H, W, C), x4.device)
-            return hip.encoder_forward(pk["encoder_struct"], x4, n, H, W, out_rows, C, ws, background=self._background)
+            return hip.encoder_forward(pk["encoder_struct"], x4, n, H, W, out_rows, C, ws)
         hs, ws = H // self.stride, W // self.stride
         x, h, w, st = self._conv(pk, "fnet.conv1", x4, n, H, W, 4, 64, 7, 2, 3, stats=True)
         lazy_stem = self.fuse_norm and self.precision == "bf16"  # relu(IN(stem)) is applied by its two consumers instead
@@ -506,13 +504,7 @@ class MVTracker(nn.Module):
     def _side_stream(self, dev):
         key = (dev.type, dev.index)
         if key not in self._side:
-            st = None
-            spec = os.environ.get("MVT_SIDE_CUS", self.side_stream_cus)  # "<n>" or "<n>:spread"; "0": an ordinary stream
-            n = int(str(spec).split(":")[0])
-            if n > 0:
-                # the encoder stream may use n of the chip's CUs only: the rest stays free for the updater's small kernels
-                st = hip.create_masked_stream(dev, n, spread=str(spec).endswith(":spread"))
-            self._side[key] = st if st is not None else torch.cuda.Stream(device=dev)
+            self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
 
     @hip.guarded
@@ -830,6 +822,8 @@ class MVTracker(nn.Module):
         idx = torch.empty(L, n, S, K, device=dev, dtype=torch.int32)
         grid = [tuple(store["xyz"][lvl].shape[2:4]) for lvl in range(L)]  # per-view (h, w) of each level
         preds = []
+        if trace is not None:  # the state every iteration's search / correlation starts from (teacher-forced parity checks)
+            trace["coords_in"], trace["ffeats_in"] = coords.clone(), ffeats.clone()
         levels = [dict(xyz=store["xyz"][lvl], P=store["P"][lvl], keys=keys[lvl], nseg=nsegs[lvl], seed_idx=idx[lvl], box=store["box"][lvl],
                        grid=store["tile_grid"][lvl], idx_out=idx[lvl], gbox=store["gbox"][lvl]) for lvl in range(L)]
         for it in range(iters):
@@ -902,6 +896,8 @@ class MVTracker(nn.Module):
                 self._lin(pk, "ffeats_updater.0", dn, C, n * S, ffeats, C, hip.ACT_GELU_ERF, R=ffeats, ldr=C)
             if trace is not None:  # (the intermediate estimates only feed the training loss upstream)
                 preds.append(coords.clone())
+                trace.setdefault("coords_iters", []).append(preds[-1])
+                trace.setdefault("ffeats_iters", []).append(ffeats.clone())
         if trace is None:
             preds.append(coords)
         vis = torch.empty(n, S, device=dev)
@@ -986,15 +982,11 @@ class MVTracker(nn.Module):
                 side = self._side_stream(dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    self._background = self.background_encoder
-                    try:
-                        for a in range(ready, T, S // 2):
-                            self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
-                            ev = torch.cuda.Event()
-                            ev.record(side)
-                            pending.append((a, ev))
-                    finally:
-                        self._background = False
+                    for a in range(ready, T, S // 2):
+                        self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        pending.append((a, ev))
         p0 = 0
         coords = vis = prev_idx = None
         while w < T - S // 2:  # mvtracker.py:537

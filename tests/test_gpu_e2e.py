@@ -377,16 +377,16 @@ def test_forward_bf16_vs_reference_autocast(model, golden, name):
     assert ebf <= 2 * d_ref and evbf <= 2 * dv_ref, (ebf, d_ref, evbf, dv_ref)
 
 
-def _check_sampled_rows(model, store, frame0, coords, feats, n_sample=64, seed=0, fcorr_tol=5e-5):
-    """Teacher-forced first refinement iteration at full size: run ONE iteration of the window on the device store, then for
-    ``n_sample`` tracks compare the kNN indices of every level (bit-exact) and the 256 correlation features per frame with the
-    oracle evaluated on the SAME store contents (copied to the host)."""
-    n, S = coords.shape[:2]
+def _check_iteration_rows(model, store, frame0, wtrace, it, sample, fcorr_tol=5e-5):
+    """Teacher-forced check of ONE refinement iteration of a traced window: the kNN indices (bit-exact, every level) and the 256
+    correlation features per frame of the tracks in ``sample`` against the oracle evaluated on the SAME store contents and on the
+    device's OWN track state before that iteration (``coords_in`` / ``coords_iters[it-1]``), so neither a neighbour flip nor an
+    upstream difference can hide or cause anything.  it >= 1 (and it == 0 of a carried track) is the SEEDED single-wave search
+    (knn_search_levels_kernel<2>: group boxes, 8x8-patch tiles, radix select), it == 0 of a new track the unseeded one."""
+    S, K = model.S, model.corr_neighbors
     T_ = store["T"]
-    tr = {}
-    model.refine_window(store, frame0, coords, torch.full((n, S), 10.0, device=DEV), torch.ones(n, S, device=DEV), feats, iters=1, trace=tr)
-    torch.cuda.synchronize()
-    sample = torch.randperm(n, generator=torch.Generator().manual_seed(seed))[:n_sample]
+    coords = wtrace["coords_in"] if it == 0 else wtrace["coords_iters"][it - 1]
+    feats = wtrace["ffeats_in"] if it == 0 else wtrace["ffeats_iters"][it - 1]
     frames = [min(frame0 + s, T_ - 1) for s in range(S)]
     c = coords[sample].cpu().permute(1, 0, 2)          # (S, m, 3)
     f = feats[sample].cpu().float().permute(1, 0, 2)   # (S, m, C)
@@ -394,13 +394,50 @@ def _check_sampled_rows(model, store, frame0, coords, feats, n_sample=64, seed=0
     for lvl in range(model.corr_n_levels):
         xyz = store["xyz"][lvl][frames].reshape(S, -1, 4)[..., :3].cpu()
         fvec = store["fvec"][lvl][frames].reshape(S, xyz.shape[1], -1).float().cpu()
-        o, idx = O.corr_sample(xyz, fvec, f, c, k=model.corr_neighbors, knn_mode="exact", return_idx=True)
-        got_idx = tr["knn_idx"][0][lvl][sample].cpu().long().permute(1, 0, 2)
-        assert torch.equal(got_idx, idx), f"kNN indices differ at level {lvl}"
-        K = model.corr_neighbors
-        got = tr["fcorrs"][0][sample].cpu().permute(1, 0, 2)[..., lvl * K * 4:(lvl + 1) * K * 4].reshape(S, n_sample, K, 4)
+        o, idx = O.corr_sample(xyz, fvec, f, c, k=K, knn_mode="exact", return_idx=True)
+        got_idx = wtrace["knn_idx"][it][lvl][sample].cpu().long().permute(1, 0, 2)
+        assert torch.equal(got_idx, idx), f"kNN indices differ at level {lvl}, iteration {it}, window frame {frame0}"
+        got = wtrace["fcorrs"][it][sample].cpu().permute(1, 0, 2)[..., lvl * K * 4:(lvl + 1) * K * 4].reshape(S, len(sample), K, 4)
         worst = max(worst, (got - o).abs().max().item())
-    assert worst < fcorr_tol, worst
+    assert worst < fcorr_tol, (worst, it, frame0)
+    return worst
+
+
+def _check_sampled_rows(model, store, frame0, coords, feats, n_sample=64, seed=0, fcorr_tol=5e-5, iters=2):
+    """Teacher-forced refinement iterations at full size on the device store: iteration 0 (unseeded search) and iteration 1 (the
+    seeded search the benchmark runs 9 times out of 12) of ``n_sample`` tracks against the oracle on the SAME store."""
+    n, S = coords.shape[:2]
+    tr = {}
+    model.refine_window(store, frame0, coords, torch.full((n, S), 10.0, device=DEV), torch.ones(n, S, device=DEV), feats, iters=iters, trace=tr)
+    torch.cuda.synchronize()
+    sample = torch.randperm(n, generator=torch.Generator().manual_seed(seed))[:n_sample]
+    return max(_check_iteration_rows(model, store, frame0, tr, it, sample, fcorr_tol) for it in range(iters))
+
+
+def _check_forward_trace(model, a, n_sample=48, iters=4, fcorr_tol=5e-5):
+    """A whole traced forward on a prebuilt store: EVERY iteration of EVERY window -- the unseeded first search of new tracks, the
+    seeded searches of iterations 1..3 and the first search of carried tracks, seeded by the previous window's neighbours through
+    the slot shift s -> s + S/2 -- teacher-forced against the oracle for sampled carried and new tracks."""
+    store = model.build_frame_store(a[0][0], a[1][0], a[3][0], a[4][0])
+    tr = []
+    model(*a, iters=iters, frame_store=store, trace=tr)
+    torch.cuda.synchronize()
+    model.check_finite()
+    assert len(tr) == len(model.last_windows) >= 2
+    p0, worst, n_carried = 0, 0.0, 0
+    for wi, ((w, p1), wt) in enumerate(zip(model.last_windows, tr)):
+        g = torch.Generator().manual_seed(100 + wi)
+        parts = []
+        if p0 > 0:
+            parts.append(torch.randperm(p0, generator=g)[:n_sample // 2])
+            n_carried += len(parts[-1])
+        if p1 > p0:
+            parts.append(p0 + torch.randperm(p1 - p0, generator=g)[:n_sample - sum(len(x) for x in parts)])
+        sample = torch.cat(parts)
+        for it in range(iters):
+            worst = max(worst, _check_iteration_rows(model, store, w, wt, it, sample, fcorr_tol))
+        p0 = p1
+    assert n_carried > 0
     return worst
 
 
@@ -447,6 +484,9 @@ def test_c3_bf16_full_size(model):
         coords, feats = _query_state(model, a, store, 0)
         w = _check_sampled_rows(model, store, 0, coords, feats)
         print(f"C3 bf16: sampled fcorr rows max abs err {w:.2e}")
+        del store
+        w = _check_forward_trace(model, a)  # 3 windows x 4 iterations, carried + new tracks, seeded searches at the C3 scale
+        print(f"C3 bf16: every window / iteration teacher-forced, fcorr rows max abs err {w:.2e}")
 
 
 def test_c2_full_size_fp32_invalid_depth(model, W):
@@ -475,6 +515,8 @@ def test_c2_full_size_fp32_invalid_depth(model, W):
         coords7, feats7 = _query_state(model, a, store, 7)  # late queries, a window that starts mid-clip
         if coords7.shape[0] >= 16:
             _check_sampled_rows(model, store, 6, coords7, feats7, n_sample=16)
+        del store
+        _check_forward_trace(model, a, n_sample=32)
 
 
 def test_c5_shard_720p_bf16(model):
@@ -496,6 +538,11 @@ def test_c5_shard_720p_bf16(model):
         coords, feats = _query_state(model, a, store, 0)
         _check_sampled_rows(model, store, 0, coords, feats, n_sample=32)
         del store
+        torch.cuda.empty_cache()
+        # carried windows at this pyramid shape (two linear-tile levels): the first 18 frames of the same clip, two windows
+        a18 = [a[0][:, :, :18], a[1][:, :, :18], a[2].clone(), a[3][:, :, :18], a[4][:, :, :18]]
+        a18[2][0, :, 0] = torch.where(a18[2][0, :, 0] > 7, torch.full_like(a18[2][0, :, 0], 7.0), a18[2][0, :, 0])
+        _check_forward_trace(model, a18, n_sample=32)
     torch.cuda.empty_cache()
 
 
@@ -582,14 +629,14 @@ def test_updater_fused_attention_bit_identical(model, n):
     with _with_precision(model, "bf16"):
         old = model.fuse_attention
         try:
-            for f in (0, 1, 2, 4, 8, 16, 23, 31):
+            for f in (0, 1, 2, 4, 16, 23):
                 model.fuse_attention = f
                 outs[f] = model.update_former(x).clone()
             torch.cuda.synchronize()
         finally:
             model.fuse_attention = old
     assert bool(torch.isfinite(outs[0]).all())
-    for f in (1, 2, 4, 8, 16, 23, 31):
+    for f in (1, 2, 4, 16, 23):
         assert torch.equal(outs[f], outs[0]), f"fuse_attention={f}: max diff {(outs[f] - outs[0]).abs().max().item():.3e}"
 
 

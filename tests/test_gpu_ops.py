@@ -658,6 +658,68 @@ def test_knn_tile_culling_is_exact(hip, patch, nseg):
             assert torch.equal(out.permute(1, 0, 2).cpu().long(), want)
 
 
+@pytest.mark.parametrize("invalid", [False, True])
+def test_knn_search_group_boxes_c3_scale(hip, invalid):
+    """The single-wave search at the scale the benchmark runs it: V*h*w = 4*128*128 points = 1 024 8x8-patch tiles in 16 group
+    boxes.  Unseeded, seeded with the neighbours of the previous positions (tight bound), and seeded with K arbitrary distinct
+    points (a valid but very loose bound: hundreds of survivors, the radix-select path): indices equal the oracle's bit for bit.
+    ``invalid``: 2 % of the points collapsed onto one location (zero depth unprojects to the camera centre) plus NaN points."""
+    g = torch.Generator().manual_seed(77 + int(invalid))
+    V, h, w, K, M, B = 4, 128, 128, 16, 96, 2
+    P = V * h * w
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    views = []
+    for v in range(V):  # four overlapping, slightly rotated sheets of one smooth surface (what fused multi-view depth looks like)
+        ang = 0.1 * v
+        x_ = xs * 0.02 * np.cos(ang) - ys * 0.02 * np.sin(ang) + 0.1 * v
+        y_ = xs * 0.02 * np.sin(ang) + ys * 0.02 * np.cos(ang)
+        z_ = 0.3 * torch.sin(x_ * 2.0) + 0.2 * torch.cos(y_ * 3.0)
+        views.append(torch.stack([x_, y_, z_], -1).reshape(h * w, 3))
+    base = torch.stack(views, 0)[None].repeat(B, 1, 1, 1)
+    xyz = (base + (torch.rand(B, V, h * w, 3, generator=g) - 0.5) * 0.02).reshape(B, P, 3)
+    if invalid:
+        bad = torch.rand(B, P, generator=g) < 0.02
+        xyz[bad] = torch.tensor([0.5, 0.5, -3.0])
+        xyz[0, 5000:5100] = float("nan")
+    pick = torch.randint(0, P, (B, M), generator=g)
+    q = torch.gather(torch.nan_to_num(xyz, nan=0.0), 1, pick[..., None].expand(B, M, 3)) + torch.randn(B, M, 3, generator=g) * 0.01
+    q[:, 0] = torch.tensor([9.0, -7.0, 3.0])   # far outside every box
+    if invalid:
+        q[:, 1] = torch.tensor([0.5, 0.5, -3.0])  # exactly on the collapsed cluster: > K equidistant candidates, lowest indices win
+    x4 = torch.zeros(B, P, 4)
+    x4[..., :3] = xyz
+    x4g = G(x4)
+    box = torch.empty(B, P // 64, 8, device=DEV)
+    hip.tile_aabb(x4g, P, B, box, (w, h))
+    gbox = torch.empty(B, P // 64 // 64, 8, device=DEV)
+    hip.tile_group_aabb(box, P, B, gbox)
+    assert gbox.shape[1] == 16
+    clean = torch.where(torch.isnan(xyz), torch.full_like(xyz, 1e18), xyz)
+
+    def search(qq, **kw):
+        out = torch.empty(M, B, K, device=DEV, dtype=torch.int32)
+        hip.knn_search(x4g, P, G(qq.permute(1, 0, 2)), M, B, 0, 1, B, K, out, box, grid=(w, h), gbox=gbox, **kw)
+        torch.cuda.synchronize()
+        return out
+
+    _, ref = O.knn_exact(K, clean, q)
+    idx = search(q)
+    assert torch.equal(idx.permute(1, 0, 2).cpu().long(), ref)
+    q2 = q + torch.randn(B, M, 3, generator=g) * 0.004
+    _, ref2 = O.knn_exact(K, clean, q2)
+    assert torch.equal(search(q2, seed_idx=idx, seed_k=K).permute(1, 0, 2).cpu().long(), ref2)
+    loose = torch.stack([torch.randperm(P, generator=g)[:K] for _ in range(M * B)]).reshape(M, B, K).int()
+    if invalid:  # a NaN seed point must not poison the bound
+        loose[:, 0, 3] = 5050
+    assert torch.equal(search(q2, seed_idx=G(loose), seed_k=K).permute(1, 0, 2).cpu().long(), ref2)
+    # the all-levels launch, in place (idx_out aliases seed_idx), as MVTracker._refine issues it
+    inpl = idx.clone()
+    hip.knn_search_levels([dict(xyz=x4g, P=P, seed_idx=inpl, box=box, grid=(w, h), idx_out=inpl, gbox=gbox)], G(q2.permute(1, 0, 2)), M, B, 0, 1, B,
+                          K, seed_k=K)
+    torch.cuda.synchronize()
+    assert torch.equal(inpl.permute(1, 0, 2).cpu().long(), ref2)
+
+
 def test_knn_levels_one_launch(hip):
     """mvt_knn_scan_levels / mvt_knn_merge_levels == the per-level calls (seeded and unseeded)."""
     g = torch.Generator().manual_seed(31)
