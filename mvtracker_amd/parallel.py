@@ -28,7 +28,8 @@ class ShardedTracker:
     def __init__(self, model, group: Optional["dist.ProcessGroup"] = None):
         self.model = model
         self.group = group
-        self._no_inplace = False
+        self.staged = os.environ.get("MVT_GATHER_STAGED", "0") != "0"  # stage the local share instead of the in-place all-gather
+        self.last_store = None  # the frame store of the last call (tests compare it with a single-rank encode)
 
     def _world(self):
         if dist.is_available() and dist.is_initialized():
@@ -50,20 +51,28 @@ class ShardedTracker:
         return out
 
     def _all_gather_in_place(self, out: torch.Tensor, rank: int, world: int) -> None:
-        """``out`` = world equal chunks along dim 0; this rank's chunk already holds its contribution."""
+        """``out`` = world equal chunks along dim 0; this rank's chunk already holds its contribution.
+
+        Which form runs is decided identically on every rank BEFORE the collective (a per-rank try / except around a collective
+        can leave ranks in different code paths): the in-place form -- the input aliases this rank's slot of the output, the
+        layout ncclAllGather documents as in-place (sendbuff == recvbuff + rank * sendcount) -- unless ``MVT_GATHER_STAGED=1``
+        asks for a staged copy of the local share (an A/B switch for a first multi-GPU bring-up; the same on all ranks because
+        the launcher exports one environment)."""
         per = out.shape[0] // world
         mine = out[rank * per:(rank + 1) * per]
-        if dist.get_backend(self.group) == "nccl" and not self._no_inplace:
-            try:
-                dist.all_gather_into_tensor(out, mine, group=self.group)  # in-place form: input aliases its slot of the output
-                return
-            except RuntimeError as e:  # a runtime that rejects the aliasing form: stage this rank's share once, from then on
-                self._no_inplace = True
-                log.warning("in-place all_gather_into_tensor rejected (%s); staging the local share", e)
+        src = mine.clone() if self.staged else mine
         if dist.get_backend(self.group) == "nccl":
-            dist.all_gather_into_tensor(out, mine.clone(), group=self.group)
-        else:
-            dist.all_gather(list(out.chunk(world, dim=0)), mine.clone(), group=self.group)
+            dist.all_gather_into_tensor(out, src, group=self.group)
+        else:  # gloo (CPU tests): the list form; c10d stages the input itself, so the aliasing input is safe
+            dist.all_gather(list(out.chunk(world, dim=0)), src, group=self.group)
+
+    @staticmethod
+    def image_share(n_img: int, world: int, rank: int):
+        """Cut of a block of ``n_img`` images across the ranks: (per, lo, hi) -- every rank owns a chunk of ``per`` image slots
+        starting at rank * per, of which [lo, hi) (block-relative) are real images; the rest of a short or empty share is zero
+        filled.  world * per - n_img <= world - 1 slots spill past the block."""
+        per = (n_img + world - 1) // world
+        return per, min(n_img, rank * per), min(n_img, (rank + 1) * per)
 
     @torch.no_grad()
     @hip.guarded
@@ -97,8 +106,7 @@ class ShardedTracker:
                 ranks idle as soon as the block has fewer frames than ranks: 12 frames on 8 GPUs); every rank encodes its
                 run of images straight into its chunk of the store and the chunks are all-gathered IN PLACE."""
                 n_img = (f1 - f0) * V
-                per = (n_img + world - 1) // world
-                lo, hi = min(n_img, rank * per), min(n_img, (rank + 1) * per)
+                per, lo, hi = self.image_share(n_img, world, rank)
                 base = f0 * V
                 dst = storage[base:base + world * per]
                 if hi > lo:
@@ -129,11 +137,10 @@ class ShardedTracker:
             elif two_blocks:  # host tensors (the gloo tests): the same two exchanges, in order
                 exchange_block(first_end, T)
                 m.fill_frame_features(store, r0, first_end, T, level0=level0)
+        self.last_store = store
         res = m(rgbs, depths, query_points[:, a:b], intrs, extrs, iters=iters, frame_store=store)
         if not gather_output:
             return res  # (the caller owns the deferred NaN check: model.check_finite())
-        if hasattr(m, "check_finite"):
-            m.check_finite()  # the outputs are gathered for the host: read the shard's NaN flag once (mvtracker.py:401-404)
         per = (N + world - 1) // world
         traj = torch.zeros(per, T, 3, device=rgbs.device)
         vis = torch.zeros(per, T, device=rgbs.device)
@@ -141,4 +148,13 @@ class ShardedTracker:
         vis[:b - a] = res["vis_e"][0].t()
         traj = self._all_gather(traj, world)[:N].permute(1, 0, 2)[None]
         vis = self._all_gather(vis, world)[:N].t()[None]
+        # The NaN guard (mvtracker.py:401-404) is a COLLECTIVE decision: a rank that raised on its own shard's flag would leave
+        # its peers blocked in the next collective.  Every rank joins every collective of the call first, the per-shard flags
+        # are max-reduced, and then all ranks raise (or none does) together -- one host read per call, after the last collective.
+        flag = getattr(m, "last_nan_flag", None)
+        if flag is not None:
+            flag = flag.clone()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if int(flag.item()) != 0:
+                raise FloatingPointError("Got NaN values in coords (on at least one query shard), perhaps the training exploded")
         return {"traj_e": traj, "vis_e": vis, "feat_init": res["feat_init"]}

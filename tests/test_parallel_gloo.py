@@ -23,6 +23,11 @@ CASES = {
     # plus 2 images of spill into the tail padding).
     "four_ranks_empty_share": (4, dict(seed=73, V=1, T=14, H=128, W=128, N=8), True),
     "four_ranks_one_block": (4, dict(seed=73, V=1, T=14, H=128, W=128, N=8), False),
+    # 8 ranks (the node size), 1 view x 14 frames: block one = 12 images, 2 per rank -> ranks 6 and 7 EMPTY; block two = 2 images,
+    # 1 per rank -> ranks 2..7 EMPTY: several ranks have empty shares in BOTH blocks; one query per rank
+    "eight_ranks_empty_shares": (8, dict(seed=74, V=1, T=14, H=128, W=128, N=8), True),
+    # the staged form of the exchange (MVT_GATHER_STAGED=1), uneven shares + spill
+    "three_ranks_staged": (3, dict(seed=72, V=2, T=15, H=96, W=96, N=10, late_queries=True, query_frames=(2, 5)), "staged"),
 }
 
 
@@ -31,7 +36,9 @@ def _worker(rank, world, port, out_path, case):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 4 else 1)
+    if CASES[case][2] == "staged":
+        os.environ["MVT_GATHER_STAGED"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import hip_mock
     from mvtracker_amd import hip, synth
@@ -47,10 +54,20 @@ def _worker(rank, world, port, out_path, case):
     sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     _, kw, overlap = CASES[case]
-    m.overlap_encoder = overlap
+    m.overlap_encoder = bool(overlap)
     clip = synth.make_clip(**kw)
     a = [torch.from_numpy(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
-    res = ShardedTracker(m)(*a, iters=2)
+    st = ShardedTracker(m)
+    assert st.staged == (overlap == "staged")
+    res = st(*a, iters=2)
+    # the exchanged level-0 store (image-granular shares, spill into the next block / the tail padding, no staging copy) must
+    # equal a single-rank encode of the same frames, image for image, on EVERY rank
+    t0 = int(a[2][0, :, 0].long().min())
+    whole = m.encode_frames(a[0][0].float(), t0, kw["T"])
+    # (the mock's CPU convolutions round differently for different batch sizes: a tolerance far below any layout error, which
+    #  would put a different IMAGE -- or zeros -- into a slot)
+    diff = (st.last_store["fvec"][0][t0:].float() - whole[t0:].float()).abs().amax(dim=(2, 3, 4))
+    assert float(diff.max()) < 1e-4 * float(whole[t0:].abs().max()), f"rank {rank}: exchanged store differs from the single-rank encode: {diff}"
     if rank == 0:
         np.savez(out_path, traj=res["traj_e"].numpy(), vis=res["vis_e"].numpy())
     dist.barrier()
