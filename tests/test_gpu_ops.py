@@ -1290,6 +1290,19 @@ def test_metrics_long_clip_and_evaluate_3dpt(hip):
         assert (np.isnan(ref[k]) and np.isnan(got[k])) or abs(ref[k] - got[k]) <= 0.011, (k, ref[k], got[k])
 
 
+@pytest.mark.parametrize("name", ["kubric", "dexycb", "panoptic_noquery", "tapvid2d", "ablation2d"])
+def test_evaluate_3dpt_vs_reference(hip, golden, name):
+    """mvtracker_amd.metrics.evaluate_3dpt (device kernel + masked means) against the flat dict the REFERENCE's
+    evaluator_3dpt.evaluate_3dpt returns for the same inputs (five evaluation settings, with and without query points)."""
+    from mvtracker_amd import metrics
+    from test_oracle_golden import check_evaluate_3dpt_against_golden
+    g = golden("evaluate_3dpt")
+    qp = g[f"{name}_qp"] if bool(g[f"{name}_with_query"][0]) else None
+    got = metrics.evaluate_3dpt(g[f"{name}_gt"], g[f"{name}_vis"], g[f"{name}_pred"], g[f"{name}_pvis"], str(g[f"{name}_setting"][0]),
+                                float(g[f"{name}_upscale"][0]), qp, add_per_track_results=False, device=DEV)
+    check_evaluate_3dpt_against_golden(g, name, got)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_concat_resize_matches_separate_resizes(hip, dt):
     """One-launch concat (whole 416-channel rows per wave) against the four mvt_resize_bilinear_ac launches it replaces and

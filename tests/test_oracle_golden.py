@@ -313,3 +313,27 @@ def test_metrics_oracle(golden, name):
     res, pt = MO.evaluate_predictions(g[f"{name}_gt"], g[f"{name}_vis"], g[f"{name}_pred"], g[f"{name}_pocc"], g[f"{name}_qp"],
                                       **METRIC_KW[name])
     check_metrics_against_golden(g, name, res, pt)
+
+
+EVAL3D_CASES = ["kubric", "dexycb", "panoptic_noquery", "tapvid2d", "ablation2d"]
+
+
+def check_evaluate_3dpt_against_golden(g, name, got, tol=0.011):
+    """The flat ``{prefix}/model__{metric}__{point_type}`` dict against the REFERENCE's (tests/golden/make_golden_evaluate3dpt.py,
+    evaluator_3dpt.py:62-173): the same key set, every value within ``tol`` (percent-scaled metrics; the reference computes in
+    float64 numpy, the product in float32 on the device), NaN where the reference has NaN (empty point-type masks)."""
+    keys = [str(k) for k in g[f"{name}_keys"]]
+    assert sorted(got) == keys, (sorted(set(keys) ^ set(got))[:5])
+    for k, ref in zip(keys, g[f"{name}_values"]):
+        v = float(got[k])
+        assert (np.isnan(ref) and np.isnan(v)) or abs(ref - v) <= tol * max(1.0, abs(ref) / 100.0), (name, k, ref, v)
+
+
+@pytest.mark.parametrize("name", EVAL3D_CASES)
+def test_evaluate_3dpt_oracle_vs_reference(golden, name):
+    from oracle import metrics_oracle as MO
+    g = golden("evaluate_3dpt")
+    qp = g[f"{name}_qp"] if bool(g[f"{name}_with_query"][0]) else None
+    got = MO.evaluate_3dpt(g[f"{name}_gt"], g[f"{name}_vis"], g[f"{name}_pred"], g[f"{name}_pvis"], str(g[f"{name}_setting"][0]),
+                           float(g[f"{name}_upscale"][0]), qp)
+    check_evaluate_3dpt_against_golden(g, name, got)
