@@ -198,6 +198,15 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # what an event pair itself costs: back-to-back records with nothing between them (the command processor's marker-to-marker
+    # latency).  It is part of every (e0, kernel, e1) interval -- a few us on a ~37 us kernel -- and is subtracted from the
+    # correlation kernel's launch times below; the raw figures stay in the JSON line (frac_raw, avg_launch_ms_raw).
+    cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+    for e0, e1 in cal:
+        e0.record()
+        e1.record()
+    torch.cuda.synchronize()
+    ev_overhead_ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in cal]))
     timing["on"] = True
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -221,18 +230,26 @@ def main():
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         store_bf16 = model.store_dtype() == torch.bfloat16
         full = [(e0.elapsed_time(e1), rows) for e0, e1, rows in corr_ev if rows == Nq * model.S]
-        kern_ms = float(np.mean([m for m, _ in full])) if full else float("nan")
+        raw_ms = float(np.mean([m for m, _ in full])) if full else float("nan")
+        kern_ms = raw_ms - ev_overhead_ms  # launch duration without the event pair's own cost
         alg = model.corr_n_levels * corr_algorithmic_bytes(Nq * model.S, model.corr_neighbors, model.latent_dim, 2 if store_bf16 else 4)
         achieved = alg / (kern_ms * 1e-3) / 1e9 if full else float("nan")
-        # HBM traffic of the roofline kernel: PMC measurement committed under profiles/ (tools/pmc_traffic.sh; counters cannot
-        # be collected from inside the timed run).  Only quoted for the workload it was measured on.
-        traffic = None
-        for name in ("r02_corr_traffic.json", "r01_corr_traffic.json"):
+        # the launches of the LAST window run alone on the chip; the earlier windows share HBM with the encoder of the later frames
+        # on the second stream.  per step: windows x iters full launches, in order
+        per_win = args.iters
+        n_full_step = len(full) // args.steps if args.steps else 0
+        alone = [m for i, (m, _) in enumerate(full) if n_full_step and (i % n_full_step) >= n_full_step - per_win]
+        alone_ms = (float(np.mean(alone)) - ev_overhead_ms) if (alone and model.overlap_encoder and n_full_step > per_win) else None
+        # HBM traffic of the roofline kernel: an OFFLINE PMC measurement committed under profiles/ (tools/pmc_traffic.sh: counters
+        # cannot be collected from inside the timed run).  Only quoted for the workload it was measured on; the source is named.
+        traffic, traffic_source = None, None
+        for name in ("r03_corr_traffic.json", "r02_corr_traffic.json", "r01_corr_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj.get("algorithmic_bytes_per_launch") == alg:
                     traffic = tj["traffic_bytes_per_launch"]
+                    traffic_source = f"profiles/{name} (offline rocprofv3 PMC passes: FETCH_SIZE, WRITE_SIZE; not measured in this run)"
                     break
         peak_tf = MFMA_F32_TFLOPS if prec == "fp32" else MFMA_BF16_TFLOPS
         upd_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in upd_ev) / args.steps
@@ -247,7 +264,9 @@ def main():
                     "flops_per_step": fl, "ms_per_step": t_ms, "calls_per_step": calls}
 
         out = {
-            "metric": "query-points*frames/sec, 4-view 24-frame 512x512 @1024 queries",
+            # (BASELINE.json's metric string for its config C3; the other workloads are labelled by their own shape)
+            "metric": "query-points*frames/sec, 4-view 24-frame 512x512 @1024 queries" if (args.config == "c3" and (V, T, H, W, Nq) == (4, 24, 512, 512, 1024))
+                      else f"query-points*frames/sec, {V}-view {T}-frame {H}x{W} @{Nq} queries",
             "value": value, "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "ms_per_step_median": float(np.median(per_step)), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
@@ -258,15 +277,17 @@ def main():
                        "queries_total": Nq * world, "parallelism": f"query-shard x{world}",
                        "frame_store": "bf16 rows" if store_bf16 else "fp32 rows"},
             "roofline": {"bound": "hbm", "kernel": "corr_gather_dot_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # `achieved` prices the ALGORITHMIC bytes; the same launch time over the HBM bytes the
-                         # PMC counters saw (neighbouring tracks share rows in L2) is the physical HBM rate
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # `achieved` prices the ALGORITHMIC bytes over the average in-situ launch duration
+                         # (all windows: two of three share HBM with the encoder stream), event-pair overhead subtracted;
+                         # `frac_alone`: the last window's launches only (nothing else on the chip); `frac_raw`: no subtraction
+                         "frac_alone": (alg / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
+                         "frac_raw": (alg / (raw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if full else None,
                          "hbm_GBps_from_traffic": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and full) else None,
                          "algorithmic_bytes_per_launch": alg, "bytes_per_unit": alg // (model.corr_n_levels * Nq * model.S),
-                         "avg_launch_ms": kern_ms, "launches_timed": len(full),
-                         # launches of the last window run alone; earlier ones share HBM with the encoder of the later
-                         # frames on the second stream (the average above includes that contention)
-                         "min_launch_ms": float(np.min([m for m, _ in full])) if full else None},
+                         "avg_launch_ms": kern_ms, "avg_launch_ms_raw": raw_ms, "event_pair_overhead_ms": ev_overhead_ms,
+                         "avg_launch_ms_alone": alone_ms, "launches_timed": len(full),
+                         "min_launch_ms": (float(np.min([m for m, _ in full])) - ev_overhead_ms) if full else None},
             "roofline_mfma": {"updater": mfma(upd_fl, upd_ms, len(upd_ev) // args.steps),
                               "encoder": mfma(enc_fl, enc_ms, len(enc_ev) // args.steps)},
         }

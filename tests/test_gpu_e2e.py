@@ -375,6 +375,87 @@ def test_forward_bf16_vs_reference_autocast(model, golden, name):
           f" | product bf16 vs reference autocast: {ebf:.2e} / {evbf:.2e}")
     assert e32 <= max(d_ref, 1e-4) and ev32 <= max(dv_ref, 1e-3), (e32, d_ref, ev32, dv_ref)
     assert ebf <= 2 * d_ref and evbf <= 2 * dv_ref, (ebf, d_ref, evbf, dv_ref)
+    # regression bound: 2 x the error measured when the bf16 path was brought up (1.0-1.15e-3 of the scene scale on tracks,
+    # 0.03-0.05 on visibility probabilities) -- the d_ref rule alone would let a 4x precision loss pass
+    assert e32 <= 2.5e-3 and ev32 <= 0.1, (e32, ev32)
+
+
+# ------------------------------------------------------------------------------------------------ round 3: bf16 stages
+BF16_STAGE_TOL = dict(encoder=(3e-2, 4e-3), updater=(3e-2, 4e-3))  # (max-abs / max-abs, mean-abs / mean-abs); measured: see the prints
+
+
+def test_encoder_bf16_vs_reference(model, golden):
+    """The benchmarked encoder (mvt_encoder_forward: bf16 MFMA convolutions, bf16 activations, fused InstanceNorm) against the
+    REFERENCE's fp32 BasicEncoder output (encoder_64x96.npz).  bf16 operand rounding through 23 convolutions."""
+    g = golden("encoder_64x96")
+    x4 = torch.zeros(2, 64, 96, 4)
+    x4[..., :3] = T(g["img"]).permute(0, 2, 3, 1)
+    with _with_precision(model, "bf16"):
+        pk = model._pack(torch.device(DEV))
+        assert "encoder_struct" in pk  # the composite library call is what the benchmark runs
+        out = torch.zeros(2, 16, 24, 128, device=DEV, dtype=model.store_dtype())
+        model._encode(pk, x4.to(DEV), 2, 64, 96, out)
+        torch.cuda.synchronize()
+    ref = g["out"]
+    got = out.float().permute(0, 3, 1, 2).cpu().numpy()
+    e_max, e_mean = np.abs(got - ref).max() / np.abs(ref).max(), np.abs(got - ref).mean() / np.abs(ref).mean()
+    print(f"encoder bf16 vs reference fp32: max {e_max:.2e} mean {e_mean:.2e}")
+    assert e_max < BF16_STAGE_TOL["encoder"][0] and e_mean < BF16_STAGE_TOL["encoder"][1], (e_max, e_mean)
+
+
+def test_updateformer_bf16_vs_reference(model, golden):
+    """The benchmarked updater (mvt_updateformer_forward: fused block kernels, in-kernel attention, hidden 256, bf16 q/k/v) against
+    the REFERENCE's fp32 EfficientUpdateFormer output (updateformer_16x12.npz)."""
+    g = golden("updateformer_16x12")
+    with _with_precision(model, "bf16"):
+        assert "updater_struct" in model._pack(torch.device(DEV))
+        out = model.update_former(T(g["x"]).to(DEV))
+        torch.cuda.synchronize()
+    ref = g["out"]
+    got = out.cpu().numpy()
+    e_max, e_mean = np.abs(got - ref).max() / np.abs(ref).max(), np.abs(got - ref).mean() / np.abs(ref).mean()
+    print(f"updater bf16 vs reference fp32: max {e_max:.2e} mean {e_mean:.2e}")
+    assert e_max < BF16_STAGE_TOL["updater"][0] and e_mean < BF16_STAGE_TOL["updater"][1], (e_max, e_mean)
+
+
+def test_refine_window_bf16_vs_reference_autocast(model, golden, W):
+    """One refinement window (3 iterations: kNN, correlation, tokens, updater, track / feature update, visibility) in bf16 mode
+    against the REFERENCE under bf16 autocast (refine_window_small_bf16.npz) and against the fp32 oracle on the same inputs.
+    Same rule as the end-to-end test -- the product must be at least as close to fp32 as the reference's autocast run is -- plus
+    absolute bounds at 2 x the measured error."""
+    g = golden("refine_window_small_bf16")
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=12, H=128, W=128, N=12)
+    a = args_of(clip)
+    feat = T(g["feat_init"])  # (1, 12, n, 128), bf16-representable values
+    n = feat.shape[2]
+    fm = O.encoder(W, 2 * (a[0].reshape(-1, 3, 128, 128) / 255.0) - 1).reshape(1, 2, 12, 128, 32, 32)
+    d = torch.nn.functional.interpolate(a[1].reshape(-1, 1, 128, 128), scale_factor=0.25, mode="nearest")
+    p32, v32 = O.refine_window(W, CFG, fm, d.reshape(1, 2, 12, 1, 32, 32), a[3], a[4], a[2][:, None, :, 1:].repeat(1, 12, 1, 1),
+                               torch.full((1, 12, n, 1), 10.0), torch.ones(1, 12, n, 1, dtype=torch.bool), feat, iters=3, knn_mode="exact")
+    ref32 = torch.stack(p32)[:, 0].permute(0, 2, 1, 3).numpy()          # (3, n, 12, 3)
+    refbf = np.transpose(g["coords_exact"][:, 0], (0, 2, 1, 3))          # reference under autocast
+    v32, vbf = v32[0].t().numpy(), g["vis_exact"][0].T
+    gdev = [t.to(DEV) for t in a]
+    with _with_precision(model, "bf16"):
+        store = model.build_frame_store(gdev[0][0], gdev[1][0], gdev[3][0], gdev[4][0])
+        coords0 = gdev[2][0, :, None, 1:].repeat(1, 12, 1)
+        tr = {}
+        mp, mvis = model.refine_window(store, 0, coords0, torch.full((n, 12), 10.0, device=DEV), torch.ones(n, 12, device=DEV),
+                                       feat[0].permute(1, 0, 2).contiguous().to(DEV), iters=3, trace=tr)
+        torch.cuda.synchronize()
+    got, gv = torch.stack(mp).cpu().numpy(), mvis.cpu().numpy()
+    sc = np.abs(ref32).max()
+    d_ref, dv_ref = np.abs(refbf - ref32).max() / sc, np.abs(vbf - v32).max()
+    e32, ev32 = np.abs(got - ref32).max() / sc, np.abs(gv - v32).max()
+    ebf, evbf = np.abs(got - refbf).max() / sc, np.abs(gv - vbf).max()
+    print(f"refine window bf16: reference autocast vs fp32 tracks {d_ref:.2e} logits {dv_ref:.2e} | product vs fp32 {e32:.2e} / {ev32:.2e} | "
+          f"product vs reference autocast {ebf:.2e} / {evbf:.2e}")
+    assert e32 <= max(d_ref, 1e-4) and ev32 <= max(dv_ref, 1e-3), (e32, d_ref, ev32, dv_ref)
+    assert ebf <= 2 * d_ref and evbf <= 2 * dv_ref, (ebf, d_ref, evbf, dv_ref)
+    assert e32 <= REFINE_BF16_TOL[0] and ev32 <= REFINE_BF16_TOL[1], (e32, ev32)
+
+
+REFINE_BF16_TOL = (2.5e-3, 0.5)  # tracks (of the scene scale), visibility LOGITS; 2 x measured
 
 
 def _check_iteration_rows(model, store, frame0, wtrace, it, sample, fcorr_tol=5e-5):
