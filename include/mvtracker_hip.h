@@ -345,6 +345,11 @@ int mvt_knn1_gather(const void* fvec, int fvec_bf16, long long P, int C, const u
  * out[(bs*N+n)*ldo + o_off + i*(2r+1)+j] for the (2r+1)^2 window around coords/2^level. */
 int mvt_window_corr(const float* fmap, const float* targets, const float* coords, float* out, int BS, int N,
                     int C, int h, int w, int level, int radius, int ldo, int o_off, void* stream);
+/* ... all pyramid levels of CorrBlock.corr_sample in ONE launch (the form the primary operator mvt_corr_gather_dot has), fp32 or
+ * bf16 maps (fmap_bf16: under autocast the reference's CorrBlock holds bf16 fmaps and bf16 avg-pooled levels, blocks.py:423-449;
+ * fp32 accumulation here).  fmaps[l] channels-last [BS][hs[l]][ws[l]][C]; out[(bs*N+n)*ldo + o_off + l*(2r+1)^2 + i*(2r+1)+j]. */
+int mvt_window_corr_levels(int levels, const void* const* fmaps, int fmap_bf16, const int* hs, const int* ws, const float* targets,
+                           const float* coords, float* out, int BS, int N, int C, int radius, int ldo, int o_off, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Token assembly and track update (mvtracker.py:324-349, 374-408; embeddings.py:35-50,

@@ -632,6 +632,94 @@ __global__ __launch_bounds__(256) void window_corr_kernel(const float* __restric
   }
 }
 
+
+// The same operator for ALL pyramid levels in one launch (grid.y = level) and for bf16 maps (BF: the feature maps of bf16 mode --
+// under autocast the reference's CorrBlock holds bf16 fmaps, blocks.py:423-449 -- 8 channels per 16-byte lane piece, so a 1-KiB
+// wave load covers 64 / LPR texels).  U wave loads are in flight before the first dot (a load -> dot -> shuffle -> LDS loop with a
+// run-time trip count pays one memory round trip per iteration).  fp32 accumulation; dots are blended exactly as above.
+struct WinLevels {
+  const void* fmap[8];
+  int h[8], w[8];
+};
+
+template <int LPR, int BF>
+__global__ __launch_bounds__(256) void window_corr_levels_kernel(WinLevels lv, const float* __restrict__ targets,
+                                                                 const float* __restrict__ coords, float* __restrict__ out, int BS, int N,
+                                                                 int radius, int ldo, int o_off) {
+  constexpr int EPL = BF ? 8 : 4;
+  constexpr int C = EPL * LPR;
+  constexpr int RPL = 64 / LPR;
+  constexpr int U = 4;
+  __shared__ float dots[4][16 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int level = blockIdx.y;
+  const long long row = (long long)blockIdx.x * 4 + wave;  // bs * N + n
+  if (row >= (long long)BS * N) return;
+  const long long bs = row / N;
+  const int h = lv.h[level], w = lv.w[level];
+  const int side = 2 * radius + 2;
+  const float inv = 1.0f / (float)(1 << level);
+  const float cx = coords[row * 2] * inv, cy = coords[row * 2 + 1] * inv;
+  const float fx0 = floorf(cx), fy0 = floorf(cy);
+  const int x0 = (int)fx0 - radius, y0 = (int)fy0 - radius;
+  const float ax = cx - fx0, ay = cy - fy0;
+  const int sub = lane / LPR, cq = lane % LPR;
+  f32x4 tg[EPL / 4];
+#pragma unroll
+  for (int e = 0; e < EPL / 4; ++e) tg[e] = *reinterpret_cast<const f32x4*>(targets + row * C + cq * EPL + 4 * e);
+  const long long img = bs * (long long)h * w * C + cq * EPL;  // element offset of this lane's channel piece in texel (0, 0)
+  const int ntex = side * side;
+  for (int t0 = 0; t0 < ntex; t0 += RPL * U) {
+    f32x4 v[U][EPL / 4];
+    int slot[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tt = t0 + u * RPL + sub;
+      const int ty = tt / side, tx = tt - ty * side;  // patch[ty][tx] = texel (x0 + tx, y0 + ty)
+      const int gx = x0 + tx, gy = y0 + ty;
+      slot[u] = tt < ntex ? ty * 16 + tx : -1;
+#pragma unroll
+      for (int e = 0; e < EPL / 4; ++e) v[u][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (tt < ntex && (unsigned)gx < (unsigned)w && (unsigned)gy < (unsigned)h) {
+        const long long off = img + ((long long)gy * w + gx) * C;
+        if (BF) {
+          const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(lv.fmap[level]) + off);
+          v[u][0] = (f32x4){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u), __uint_as_float(q.y << 16),
+                            __uint_as_float(q.y & 0xFFFF0000u)};
+          v[u][EPL / 4 - 1] = (f32x4){__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xFFFF0000u), __uint_as_float(q.w << 16),
+                                      __uint_as_float(q.w & 0xFFFF0000u)};
+        } else {
+          v[u][0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lv.fmap[level]) + off);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float d = tg[0][0] * v[u][0][0];
+      d = fmaf(tg[0][1], v[u][0][1], d);
+      d = fmaf(tg[0][2], v[u][0][2], d);
+      d = fmaf(tg[0][3], v[u][0][3], d);
+      if (BF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d = fmaf(tg[EPL / 4 - 1][e], v[u][EPL / 4 - 1][e], d);
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      if (cq == 0 && slot[u] >= 0) dots[wave][slot[u]] = d;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int win = 2 * radius + 1;
+  const float scale = sqrtf((float)C);
+  for (int o = lane; o < win * win; o += 64) {
+    const int a = o / win, b = o - a * win;  // sample at (cx + a - r, cy + b - r): first index runs along x
+    const float d00 = dots[wave][b * 16 + a], d01 = dots[wave][b * 16 + a + 1];
+    const float d10 = dots[wave][(b + 1) * 16 + a], d11 = dots[wave][(b + 1) * 16 + a + 1];
+    const float val = (1.f - ay) * ((1.f - ax) * d00 + ax * d01) + ay * ((1.f - ax) * d10 + ax * d11);
+    out[row * ldo + o_off + level * win * win + o] = val / scale;
+  }
+}
+
 }  // namespace
 
 extern "C" int mvt_tile_aabb(const float* xyz, long long P, int T, int grid_w, int grid_h, float* box, void* stream) {
@@ -865,6 +953,44 @@ extern "C" int mvt_window_corr(const float* fmap, const float* targets, const fl
     case 128: LAUNCH(32); break;
     case 256: LAUNCH(64); break;
     default: return MVT_ERR_ARG;
+  }
+#undef LAUNCH
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_window_corr_levels(int levels, const void* const* fmaps, int fmap_bf16, const int* hs, const int* ws, const float* targets,
+                                      const float* coords, float* out, int BS, int N, int C, int radius, int ldo, int o_off, void* stream) {
+  MVT_REQUIRE(levels >= 1 && levels <= 8 && fmaps && hs && ws && targets && coords && out && BS > 0 && N > 0);
+  MVT_REQUIRE((fmap_bf16 == 0 || fmap_bf16 == 1) && radius >= 1 && radius <= 7 && o_off >= 0);
+  MVT_REQUIRE(ldo >= o_off + levels * (2 * radius + 1) * (2 * radius + 1));
+  WinLevels lv{};
+  for (int l = 0; l < levels; ++l) {
+    MVT_REQUIRE(fmaps[l] && hs[l] > 0 && ws[l] > 0 && ((uintptr_t)fmaps[l] % 16 == 0) && (long long)BS * hs[l] * ws[l] * C < (1LL << 40));
+    lv.fmap[l] = fmaps[l];
+    lv.h[l] = hs[l];
+    lv.w[l] = ws[l];
+  }
+  MVT_REQUIRE((uintptr_t)targets % 16 == 0);
+  const dim3 grid((unsigned)mvt_cdiv((long long)BS * N, 4), (unsigned)levels);
+#define LAUNCH(LPR, BF)                                                                                                                  \
+  hipLaunchKernelGGL((window_corr_levels_kernel<LPR, BF>), grid, dim3(256), 0, mvt_stream(stream), lv, targets, coords, out, BS, N, radius, \
+                     ldo, o_off)
+  if (fmap_bf16) {
+    switch (C) {
+      case 32: LAUNCH(4, 1); break;
+      case 64: LAUNCH(8, 1); break;
+      case 128: LAUNCH(16, 1); break;
+      case 256: LAUNCH(32, 1); break;
+      default: return MVT_ERR_ARG;
+    }
+  } else {
+    switch (C) {
+      case 32: LAUNCH(8, 0); break;
+      case 64: LAUNCH(16, 0); break;
+      case 128: LAUNCH(32, 0); break;
+      case 256: LAUNCH(64, 0); break;
+      default: return MVT_ERR_ARG;
+    }
   }
 #undef LAUNCH
   return mvt_launch_status();

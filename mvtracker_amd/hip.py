@@ -66,6 +66,7 @@ SIGNATURES = {
     "mvt_corr_gather_dot": [I, P, P, I, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
     "mvt_knn1_gather": [P, I, LL, I, P, I, I, I, P, P, P],
     "mvt_window_corr": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "mvt_window_corr_levels": [I, P, I, P, P, P, P, P, I, I, I, I, I, I, P],
     "mvt_pos_embed": [P, I, I, I, I, P, P, P],
     "mvt_token_assemble": [P, P, I, P, I, P, P, P, I, I, I, P, I, P],
     "mvt_delta_split": [P, I, P, P, P, P, LL, I, P, P],
@@ -415,6 +416,15 @@ def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):
 def window_corr(fmap, targets, coords, out, BS, N, Cc, h, w, level, radius, ldo, o_off):
     _call("mvt_window_corr", _ptr(fmap), _ptr(targets), _ptr(coords), _ptr(out), BS, N, Cc, h, w, level, radius, ldo, o_off,
           _stream())
+
+
+def window_corr_levels(fmaps, targets, coords, out, BS, N, Cc, radius, ldo, o_off=0):
+    """CorrBlock.corr_sample for all levels in one launch; fmaps: list of channels-last (BS,h,w,C) device tensors, fp32 or bf16."""
+    n = len(fmaps)
+    bf = fmaps[0].dtype == torch.bfloat16
+    assert all((f.dtype == torch.bfloat16) == bf and f.is_contiguous() and f.shape[0] == BS and f.shape[3] == Cc for f in fmaps)
+    _call("mvt_window_corr_levels", n, (C.c_void_p * n)(*[_ptr(f) for f in fmaps]), 1 if bf else 0, (C.c_int * n)(*[f.shape[1] for f in fmaps]),
+          (C.c_int * n)(*[f.shape[2] for f in fmaps]), _ptr(_f32c(targets)), _ptr(_f32c(coords)), _ptr(out), BS, N, Cc, radius, ldo, o_off, _stream())
 
 
 def pos_embed(coords, N, S, D, dim_padded, pos, omega=None):

@@ -128,6 +128,7 @@ class MVTracker(nn.Module):
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
         self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
+        self.defer_encoder = os.environ.get("MVT_ENC_DEFER", "1") != "0"  # one block of later frames per window on the side stream
         self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
         self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
         self.fuse_tokens = os.environ.get("MVT_FUSE_TOKENS", "1") != "0"  # ... with the token rows assembled inside that launch
@@ -506,6 +507,20 @@ class MVTracker(nn.Module):
         if key not in self._side:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
+
+    def _encode_on_side_stream(self, store, rgbs, firsts, pending):
+        """Encode the S/2-frame blocks starting at ``firsts`` on the second HIP stream (ordered after everything enqueued on the
+        caller's stream so far); ``pending`` receives (first frame, event) per block."""
+        dev = rgbs.device
+        T, S = rgbs.shape[1], self.S
+        side = self._side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for a in firsts:
+                self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
+                ev = torch.cuda.Event()
+                ev.record(side)
+                pending.append((a, ev))
 
     @hip.guarded
     def fill_frame_features(self, store, rgbs, a, b, level0=None):
@@ -966,6 +981,7 @@ class MVTracker(nn.Module):
         w = int(qt_s.min())
         windows = []
         pending = []  # (first frame, event): feature chunks being encoded on the side stream
+        side_chunks = []  # first frames of the blocks the side stream has not been given yet
         if w < T - S // 2:
             if frame_store is not None:
                 store = frame_store
@@ -978,15 +994,10 @@ class MVTracker(nn.Module):
                 # CUs, the encoder's convolutions take the rest.
                 ready = max(w, 0) + S
                 store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), t1=ready)
-                main = torch.cuda.current_stream(dev)
-                side = self._side_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    for a in range(ready, T, S // 2):
-                        self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
-                        ev = torch.cuda.Event()
-                        ev.record(side)
-                        pending.append((a, ev))
+                side_chunks = list(range(ready, T, S // 2))  # first frames of the S/2-frame blocks still to encode
+                if not self.defer_encoder:
+                    self._encode_on_side_stream(store, rgbs, side_chunks, pending)
+                    side_chunks = []
         p0 = 0
         coords = vis = prev_idx = None
         while w < T - S // 2:  # mvtracker.py:537
@@ -994,6 +1005,11 @@ class MVTracker(nn.Module):
             assert p1 > 0
             while pending and pending[0][0] < w + S:  # the frames this window reads must have left the encoder
                 torch.cuda.current_stream(dev).wait_event(pending.pop(0)[1])
+            if side_chunks:
+                # one block of later frames per window: block j is what window j + 1 will read, so it is encoded WHILE window j is
+                # refined -- its convolutions fill the CUs the 64 virtual tracks' kernels leave idle -- instead of all blocks
+                # piling onto the first window (which then runs at half speed while the last windows run alone)
+                self._encode_on_side_stream(store, rgbs, [side_chunks.pop(0)], pending)
             if p1 > p0:  # feature init: 1-NN in the fused level-0 cloud of the query frame (:607-645)
                 P0 = store["P"][0]
                 ns = self._nseg(P0, 1)

@@ -381,12 +381,23 @@ def test_forward_bf16_vs_reference_autocast(model, golden, name):
 
 
 # ------------------------------------------------------------------------------------------------ round 3: bf16 stages
-BF16_STAGE_TOL = dict(encoder=(3e-2, 4e-3), updater=(3e-2, 4e-3))  # (max-abs / max-abs, mean-abs / mean-abs); measured: see the prints
+def _bf16_stage_check(name, got, ref, autocast_out, cap):
+    """A bf16 stage against the REFERENCE's fp32 fixture.  The bar is what bf16 autocast costs the reference itself on the same
+    input (the oracle under torch.autocast is bit-identical to the reference under autocast, tests/test_oracle_golden.py): the
+    product may be at most 10 % worse than that, in the max-abs and in the mean-abs sense (both relative to the fixture's scale),
+    and below an absolute cap of ~2 x the error measured when the test was written (regression guard)."""
+    sc_max, sc_mean = np.abs(ref).max(), np.abs(ref).mean()
+    e_max, e_mean = np.abs(got - ref).max() / sc_max, np.abs(got - ref).mean() / sc_mean
+    d_max, d_mean = np.abs(autocast_out - ref).max() / sc_max, np.abs(autocast_out - ref).mean() / sc_mean
+    print(f"{name} bf16 vs reference fp32: max {e_max:.2e} mean {e_mean:.2e} | reference under autocast: max {d_max:.2e} mean {d_mean:.2e}")
+    assert e_max <= 1.1 * d_max and e_mean <= 1.1 * d_mean, (e_max, d_max, e_mean, d_mean)
+    assert e_max <= cap[0] and e_mean <= cap[1], (e_max, e_mean, cap)
 
 
-def test_encoder_bf16_vs_reference(model, golden):
+def test_encoder_bf16_vs_reference(model, golden, W):
     """The benchmarked encoder (mvt_encoder_forward: bf16 MFMA convolutions, bf16 activations, fused InstanceNorm) against the
-    REFERENCE's fp32 BasicEncoder output (encoder_64x96.npz).  bf16 operand rounding through 23 convolutions."""
+    REFERENCE's fp32 BasicEncoder output (encoder_64x96.npz).  bf16 operand rounding through 23 convolutions: measured max 2.5e-2 /
+    mean 2.2e-2 of the output scale, the reference under autocast 2.7e-2 / 2.5e-2."""
     g = golden("encoder_64x96")
     x4 = torch.zeros(2, 64, 96, 4)
     x4[..., :3] = T(g["img"]).permute(0, 2, 3, 1)
@@ -396,26 +407,22 @@ def test_encoder_bf16_vs_reference(model, golden):
         out = torch.zeros(2, 16, 24, 128, device=DEV, dtype=model.store_dtype())
         model._encode(pk, x4.to(DEV), 2, 64, 96, out)
         torch.cuda.synchronize()
-    ref = g["out"]
-    got = out.float().permute(0, 3, 1, 2).cpu().numpy()
-    e_max, e_mean = np.abs(got - ref).max() / np.abs(ref).max(), np.abs(got - ref).mean() / np.abs(ref).mean()
-    print(f"encoder bf16 vs reference fp32: max {e_max:.2e} mean {e_mean:.2e}")
-    assert e_max < BF16_STAGE_TOL["encoder"][0] and e_mean < BF16_STAGE_TOL["encoder"][1], (e_max, e_mean)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ac = O.encoder(W, T(g["img"])).float().numpy()
+    _bf16_stage_check("encoder", out.float().permute(0, 3, 1, 2).cpu().numpy(), g["out"], ac, (5e-2, 4.5e-2))
 
 
-def test_updateformer_bf16_vs_reference(model, golden):
+def test_updateformer_bf16_vs_reference(model, golden, W):
     """The benchmarked updater (mvt_updateformer_forward: fused block kernels, in-kernel attention, hidden 256, bf16 q/k/v) against
-    the REFERENCE's fp32 EfficientUpdateFormer output (updateformer_16x12.npz)."""
+    the REFERENCE's fp32 EfficientUpdateFormer output (updateformer_16x12.npz); the reference under autocast: max 1.1e-2 / mean 9e-3."""
     g = golden("updateformer_16x12")
     with _with_precision(model, "bf16"):
         assert "updater_struct" in model._pack(torch.device(DEV))
         out = model.update_former(T(g["x"]).to(DEV))
         torch.cuda.synchronize()
-    ref = g["out"]
-    got = out.cpu().numpy()
-    e_max, e_mean = np.abs(got - ref).max() / np.abs(ref).max(), np.abs(got - ref).mean() / np.abs(ref).mean()
-    print(f"updater bf16 vs reference fp32: max {e_max:.2e} mean {e_mean:.2e}")
-    assert e_max < BF16_STAGE_TOL["updater"][0] and e_mean < BF16_STAGE_TOL["updater"][1], (e_max, e_mean)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ac = O.update_former(W, T(g["x"]), CFG).float().numpy()
+    _bf16_stage_check("updater", out.cpu().numpy(), g["out"], ac, (2.5e-2, 2e-2))
 
 
 def test_refine_window_bf16_vs_reference_autocast(model, golden, W):
@@ -621,7 +628,7 @@ def test_c5_shard_720p_bf16(model):
         del store
         torch.cuda.empty_cache()
         # carried windows at this pyramid shape (two linear-tile levels): the first 18 frames of the same clip, two windows
-        a18 = [a[0][:, :, :18], a[1][:, :, :18], a[2].clone(), a[3][:, :, :18], a[4][:, :, :18]]
+        a18 = [a[0][:, :, :18].contiguous(), a[1][:, :, :18].contiguous(), a[2].clone(), a[3][:, :, :18].contiguous(), a[4][:, :, :18].contiguous()]
         a18[2][0, :, 0] = torch.where(a18[2][0, :, 0] > 7, torch.full_like(a18[2][0, :, 0], 7.0), a18[2][0, :, 0])
         _check_forward_trace(model, a18, n_sample=32)
     torch.cuda.empty_cache()
