@@ -845,11 +845,13 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
           auto row = [&](int j) { return mt + j; };
           attn_load<1, 1>(fr[i], p.aq, p.ldaq, row, p.S, p.ak, p.av, p.ldakv, row, p.S, ok[i] ? hd : 0, lane);
         }
+        STAMP(49);
 #pragma unroll
         for (int i = 0; i < MAXU; ++i) {
           const int u = u0 + 8 * i;
           const int tr = u / 6, hd = u - tr * 6;
           if (ok[i]) attn_compute<1, 1>(fr[i], p.S, p.S, hd, vt, zrow, As, LDA, tr * p.S, lane);
+          STAMP(50 + i);
           if (i == 2 && u0 == wave) {
             // (not earlier: the operands of the pending units still occupy the registers; the empty asm keeps the sixteen fragment
             //  addresses from being computed ahead of the loop and spilled)

@@ -128,7 +128,7 @@ class MVTracker(nn.Module):
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
         self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
-        self.defer_encoder = os.environ.get("MVT_ENC_DEFER", "1") != "0"  # one block of later frames per window on the side stream
+        self.defer_encoder = os.environ.get("MVT_ENC_DEFER", "0") != "0"  # one block of later frames per window on the side stream (A/B: no gain at C3)
         self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
         self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
         self.fuse_tokens = os.environ.get("MVT_FUSE_TOKENS", "1") != "0"  # ... with the token rows assembled inside that launch
