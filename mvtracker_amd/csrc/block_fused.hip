@@ -70,6 +70,18 @@ __device__ unsigned long long mvt_stamp_buf[2 * 8 * 64];
   } while (0)
 #endif
 
+#ifdef MVT_STAMPS
+#define ASTAMP(i)                                       \
+  do {                                                  \
+    const int wave = threadIdx.x >> 6;                  \
+    STAMP(i);                                           \
+  } while (0)
+#else
+#define ASTAMP(i) \
+  do {            \
+  } while (0)
+#endif
+
 struct BlockArgs {
   float* x;                  // [M][ldx] tokens, updated in place
   int ldx;
@@ -313,11 +325,51 @@ __device__ __forceinline__ void attn_load(AttnFrags<NMBQ, NKB>& f, const unsigne
 __device__ __forceinline__ f32x4 bf4_to_f32(unsigned lo, unsigned hi) {
   return (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xFFFF0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
 }
+// Reductions over the lane pair (l, l ^ 32) without an LDS round trip (gfx950 v_permlane32_swap): with both operands = v the two
+// results hold, in every lane, the values of the pair's lower and of its upper lane.
+__device__ __forceinline__ float pair_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
+// bd > 0: BLOCK-DIAGONAL attention -- query i only sees the keys j with j / bd == i / bd.  That is the time attention of a tile of
+// whole tracks (bd = S frames per track, rows track-major): all tracks of the tile go through ONE unit per head (32 * NMBQ queries x
+// 32 * NKB keys, the cross-track scores masked) instead of one 32 x 32 unit per (track, head) -- the S x S attention of a single
+// track fills 14 % of a 32 x 32 MFMA tile, and a unit's cost is its dependent chain (operand fetch, three chained MFMAs, softmax,
+// V^T staging, P.V), not its arithmetic.
+// Softmax in ONE pass over all NKB key blocks (scores of every key block first, then max / exp / sum once): no running maximum,
+// no rescaling of the output accumulators between key blocks.
 template <int NMBQ, int NKB>
 __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int nq, int nk, int hd, unsigned short* vt,
-                                             const unsigned short* zrow, unsigned short* As, int lda, int arow0, int lane) {
+                                             const unsigned short* zrow, unsigned short* As, int lda, int arow0, int lane, int bd = 0,
+                                             int vstride = 0) {
   const int r = lane & 31, h = lane >> 5;
   const float scale = 1.0f / sqrtf((float)DHA);
+  // V^T images: vstride > 0: one image per key block (vt + kb * vstride), all staged HERE, once, ahead of everything else (their
+  // LDS round trip passes under the score MFMAs); vstride == 0: a single image, restaged per key block inside the query-block loop
+  // (only sensible with one query block)
+  auto stage_vt = [&](int kb, unsigned short* img) {
+    const int key = kb * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      u32x2 w = f.v[kb][i];
+      if (key >= nk) w = (u32x2){0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) img[(24 * h + 4 * i + e) * LDVA + r] = (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xFFFFu));
+    }
+  };
+  if (vstride > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) stage_vt(kb, vt + kb * vstride);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  __builtin_amdgcn_sched_barrier(0);  // (phase boundaries pinned: left free, the scheduler interleaves the V^T stores, the score
+  ASTAMP(49);                         //  MFMAs and the softmax into a stream that measured 10 k cycles slower per unit)
   bf16x8 qf[NMBQ][3];
 #pragma unroll
   for (int mb = 0; mb < NMBQ; ++mb) {
@@ -337,75 +389,77 @@ __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int 
       }
     }
   }
-  f32x16 oacc[NMBQ][2];
-  float m[NMBQ], l[NMBQ];
+  // key blocks whose second half (keys 16..31 of the block: accumulator registers 8..15, the second P.V k-step) does not exist --
+  // the S = 12 keys of a lone track: their scores are -inf, their probabilities exactly 0 and their products add +0, so leaving
+  // them out (wave-uniform) changes no bit of the result and saves half of the exponentials and P.V MFMAs
+  const unsigned bdm = bd > 0 ? (65536u / (unsigned)bd + 1u) : 0u;  // j / bd == (j * bdm) >> 16 for j < 64 <= 2^16 / bd
 #pragma unroll
   for (int mb = 0; mb < NMBQ; ++mb) {
-    m[mb] = -INFINITY;
-    l[mb] = 0.f;
+    const int qi = mb * 32 + r;
+    const unsigned qt = ((unsigned)qi * bdm) >> 16;
+    f32x16 sc[NKB];
+    float mx = -INFINITY;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[mb][db][e] = 0.f;
-  }
+      for (int e = 0; e < 16; ++e) sc[kb][e] = 0.f;
 #pragma unroll
-  for (int kb = 0; kb < NKB; ++kb) {
-    const int key = kb * 32 + r;
-    bf16x8 kf[3];
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) kf[ks] = __builtin_bit_cast(bf16x8, f.k[kb][ks]);
-    {
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        u32x2 w = f.v[kb][i];
-        if (key >= nk) w = (u32x2){0u, 0u};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vt[(24 * h + 4 * i + e) * LDVA + r] = (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xFFFFu));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      for (int ks = 0; ks < 3; ++ks) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.k[kb][ks]), qf[mb][ks], sc[kb], 0, 0, 0);
     }
+    // (registers 8..15 of a block = its keys 16..31: left out, wave-uniformly, when they do not exist -- see above; static register
+    //  indices everywhere: a run-time trip count inside these unrolled loops would turn them into indexed register accesses)
 #pragma unroll
-    for (int mb = 0; mb < NMBQ; ++mb) {
-      f32x16 sc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sc[e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[mb][ks], sc, 0, 0, 0);
-      // keys 16.. of this block (accumulator registers 8..15, the second PV k-step) do not exist when nk <= kb*32 + 16 -- the time
-      // attention's S = 12: their scores are -inf, their probabilities exactly 0 and their PV products add +0, so leaving them out
-      // (wave-uniform branch) changes no bit of the result and saves half of the exponentials and PV MFMAs
+    for (int kb = 0; kb < NKB; ++kb) {
       const bool half = nk <= kb * 32 + 16;
-      float mx = -INFINITY;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int kk = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (kk >= nk) sc[e] = -INFINITY;
-        mx = fmaxf(mx, sc[e]);
+        // (branch-free: as `a && (b || c)` every element became its own divergent branch -- 32 x ~25 instructions with exec
+        //  save / restore; bdm == 0 without a block-diagonal mask, so both track numbers are 0 and the compare always holds)
+        const unsigned kk = (unsigned)(kb * 32 + (e & 3) + 8 * (e >> 2)) + 4u * (unsigned)h;
+        const bool ok = (kk < (unsigned)nk) & (((kk * bdm) >> 16) == qt);
+        sc[kb][e] = ok ? sc[kb][e] : -INFINITY;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m[mb], mx);
-      const float corr = (m[mb] == -INFINITY) ? 0.f : __expf(m[mb] - mn);
-      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, sc[kb][e]);
+      if (!half) {
+#pragma unroll
+        for (int e = 8; e < 16; ++e) mx = fmaxf(mx, sc[kb][e]);
+      }
+    }
+    mx = pair_max(mx);
+    if (mx == -INFINITY) mx = 0.f;  // (a padding query past nq: every key masked; its column is never stored)
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bool half = nk <= kb * 32 + 16;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        sc[e] = __expf(sc[e] - mn);
-        ps += sc[e];
+        sc[kb][e] = __expf(sc[kb][e] - mx);
+        ps += sc[kb][e];
       }
       if (!half) {
 #pragma unroll
         for (int e = 8; e < 16; ++e) {
-          sc[e] = __expf(sc[e] - mn);
-          ps += sc[e];
+          sc[kb][e] = __expf(sc[kb][e] - mx);
+          ps += sc[kb][e];
         }
       }
-      l[mb] = l[mb] * corr + ps;
-      m[mb] = mn;
-      if (__ballot(corr != 1.0f)) {
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(50 + 2 * mb);
+    f32x16 oacc[2];
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) oacc[mb][db][e] *= corr;
+      for (int e = 0; e < 16; ++e) oacc[db][e] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const bool half = nk <= kb * 32 + 16;
+      const unsigned short* vimg = vt + kb * vstride;
+      if (vstride == 0 && (mb == 0 || NKB > 1)) {  // single image: restaged per key block (NKB 1: staged once)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        stage_vt(kb, vt);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       }
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
@@ -413,8 +467,8 @@ __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int 
         f32x4 lo4, hi4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          lo4[e] = sc[8 * sk + e];
-          hi4[e] = sc[8 * sk + 4 + e];
+          lo4[e] = sc[kb][8 * sk + e];
+          hi4[e] = sc[kb][8 * sk + 4 + e];
         }
         const bf16x4 bl = __builtin_convertvector(lo4, bf16x4), bh = __builtin_convertvector(hi4, bf16x4);
         bf16x8 pb;
@@ -425,19 +479,17 @@ __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int 
         }
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const unsigned short* vr = (db * 32 + r < DHA) ? &vt[(db * 32 + r) * LDVA + 16 * sk + 4 * h] : zrow + 16 * sk + 4 * h;
+          const unsigned short* vr = (db * 32 + r < DHA) ? &vimg[(db * 32 + r) * LDVA + 16 * sk + 4 * h] : zrow + 16 * sk + 4 * h;
           const u32x2 a0 = *reinterpret_cast<const u32x2*>(vr), a1 = *reinterpret_cast<const u32x2*>(vr + 8);
           const bf16x8 va = __builtin_bit_cast(bf16x8, (u32x4){a0[0], a0[1], a1[0], a1[1]});
-          oacc[mb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, oacc[mb][db], 0, 0, 0);
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, oacc[db], 0, 0, 0);
         }
       }
     }
-  }
-#pragma unroll
-  for (int mb = 0; mb < NMBQ; ++mb) {
-    const float lt = l[mb] + __shfl_xor(l[mb], 32, 64);
+    __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(51 + 2 * mb);
+    const float lt = pair_sum(ps);
     const float inv = 1.0f / lt;
-    const int qi = mb * 32 + r;
     if (qi >= nq) continue;
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
@@ -447,7 +499,7 @@ __device__ __forceinline__ void attn_compute(const AttnFrags<NMBQ, NKB>& f, int 
         if (d < DHA) {
           f32x4 t;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = oacc[mb][db][4 * gq + e] * inv;
+          for (int e = 0; e < 4; ++e) t[e] = oacc[db][4 * gq + e] * inv;
           *reinterpret_cast<u32x2*>(&As[(arow0 + qi) * lda + hd * DHA + d]) = __builtin_bit_cast(u32x2, __builtin_convertvector(t, bf16x4));
         }
       }
@@ -595,8 +647,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   auto prefetch_wo = [&]() { fill_wq(wq, wo_row); };
   if (HAS_MLP && !outp) {
     fill_wq(wq, fc1_first);
-  } else if (outp && ATT != 1) {
-    prefetch_wo();  // (time attention: after the second unit, when its operand registers are free -- see below)
+  } else if (outp) {
+    prefetch_wo();
   } else if (EARLY && MODE == 2) {
     const int nb0e = (int)blockIdx.y * 8 + wave;
     if (active(0) && nb0e < (p.next[0].N + 31) / 32) {
@@ -823,47 +875,28 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     unsigned short* zrow = reinterpret_cast<unsigned short*>(st);
     if (t < 48) zrow[t] = 0;
     constexpr int XW = (BM * LDX) / VTA;  // images that fit Xs
-    unsigned short* vt = wave < XW ? &Xs[wave * VTA] : &Hs[0][0] + ((BM * LDA + 7) & ~7) + (wave - XW) * VTA;
-    static_assert(XW + (2 * BM * LDH - BM * LDA - 8) / VTA >= 6, "six V^T images fit beside the attention tile");
+    // NMB 2 (64-row tiles): TWO images per attention wave (one per key block, staged once): waves 0..3 in Xs, waves 4, 5 behind As;
+    // NMB 1: one image per wave (four in Xs, two behind As), restaged per key block
+    constexpr int VPW = NMB == 2 ? 2 : 1;
+    constexpr int XWV = XW / VPW;  // waves whose images live in Xs
+    unsigned short* vt = wave < XWV ? &Xs[wave * VPW * VTA] : &Hs[0][0] + ((BM * LDA + 7) & ~7) + (wave - XWV) * VPW * VTA;
+    constexpr int vstride = VPW == 2 ? VTA : 0;
+    static_assert(XWV + ((2 * BM * LDH - BM * LDA - 8) / VTA) / VPW >= 6, "the V^T images of six waves fit beside the attention tile");
     __syncthreads();
     STAMP(1);
     if (ATT == 1) {
-      // units (track, head) are dealt round-robin to the waves; the operands of ALL of a wave's units are fetched first (one
-      // exposed memory latency instead of one per unit), then the units are computed back to back
-      const int ntr = bmv / p.S;
-      constexpr int MAXU = 4;  // ceil(5 tracks x 6 heads / 8 waves); more tracks per tile (S < 12) loop over groups of MAXU
-      for (int u0 = wave; u0 < ntr * 6; u0 += 8 * MAXU) {
-        AttnFrags<1, 1> fr[MAXU];
-        bool ok[MAXU];
-#pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-          const int u = u0 + 8 * i;
-          const int tr = u / 6, hd = u - tr * 6;
-          long long mt = m0 + (long long)tr * p.S;  // first row of the track
-          ok[i] = u < ntr * 6 && mt < p.M;
-          if (!ok[i]) mt = m0;  // (a valid address; the fragments are not used)
-          auto row = [&](int j) { return mt + j; };
-          attn_load<1, 1>(fr[i], p.aq, p.ldaq, row, p.S, p.ak, p.av, p.ldakv, row, p.S, ok[i] ? hd : 0, lane);
-        }
-        STAMP(49);
-#pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-          const int u = u0 + 8 * i;
-          const int tr = u / 6, hd = u - tr * 6;
-          if (ok[i]) attn_compute<1, 1>(fr[i], p.S, p.S, hd, vt, zrow, As, LDA, tr * p.S, lane);
-          STAMP(50 + i);
-          if (i == 2 && u0 == wave) {
-            // (not earlier: the operands of the pending units still occupy the registers; the empty asm keeps the sixteen fragment
-            //  addresses from being computed ahead of the loop and spilled)
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned short* wr = wo_row;
-            asm volatile("" : "+v"(wr));
-            fill_wq(wq, wr);
-            __builtin_amdgcn_sched_barrier(0);
-          }  // the operand registers of three units are free: the round trip passes under the last
-        }
+      // Time attention of the tile's whole tracks (rows track-major: row = track * S + frame): one BLOCK-DIAGONAL unit per head --
+      // 64 queries x 64 keys, query i sees the keys of its own track only -- on waves 0..5.  (Round 2 ran one 32 x 32 unit per
+      // (track, head): 30 units dealt to the 8 waves, four dependent chains per wave, 384 operand loads per workgroup; in-kernel
+      // stamps: 24-30 k of the kernel's 102 k cycles.)
+      const long long left = p.M - m0;
+      const int nrow = left < bmv ? (int)left : bmv;
+      if (wave < 6 && nrow > 0) {
+        auto row = [&](int j) { return m0 + j; };
+        AttnFrags<NMB, 2> fr;
+        attn_load<NMB, 2>(fr, p.aq, p.ldaq, row, nrow, p.ak, p.av, p.ldakv, row, nrow, wave, lane);
+        attn_compute<NMB, 2>(fr, nrow, nrow, wave, vt, zrow, As, LDA, 0, lane, p.S, vstride);
       }
-      if (ntr * 6 <= wave) prefetch_wo();  // (a wave without units)
     } else if (wave < 6 && grow(0) >= 0) {
       const long long left = ntok - (long long)blockIdx.x * BM;
       const int nq = left < BM ? (int)left : BM;
@@ -871,7 +904,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       auto krow = [&](int j) { return (long long)j * p.S + (long long)blockIdx.z; };
       AttnFrags<NMB, 2> fr;
       attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, lane);
-      attn_compute<NMB, 2>(fr, nq, p.nkeys, wave, vt, zrow, As, LDA, 0, lane);
+      attn_compute<NMB, 2>(fr, nq, p.nkeys, wave, vt, zrow, As, LDA, 0, lane, 0, vstride);
     }
     pre_gemm();
     STAMP(2);

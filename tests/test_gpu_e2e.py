@@ -707,11 +707,15 @@ def test_updateformer_hidden_384_golden(golden, prec, tol):
 
 
 @pytest.mark.parametrize("n", [16, 1024, 37])
-def test_updater_fused_attention_bit_identical(model, n):
-    """Attention inside the block kernels (mvt_attn_block_fused_bf16: time / point<-virtual / virtual-self) performs the same
-    arithmetic in the same order as the separate attention launches: the updater output must be IDENTICAL, bit for bit, for
-    every combination -- n = 1024 is the C3 shape (tiles straddling the point / virtual boundary, 60-row track tiles),
-    n = 37 leaves partial tiles everywhere, n = 16 takes the small-M form of the point blocks."""
+def test_updater_fused_attention_matches_separate_launches(model, n):
+    """Attention inside the block kernels (mvt_attn_block_fused_bf16: time / point<-virtual / virtual-self, partial merge in the
+    block prologue) against the separate attention launches -- n = 1024 is the C3 shape (tiles straddling the point / virtual
+    boundary, 60-row track tiles), n = 37 leaves partial tiles everywhere, n = 16 takes the small-M form of the point blocks.
+    Round 3: the in-kernel attention is no longer the arithmetic of attention_mfma_kernel in the same order (one softmax pass over
+    all key blocks instead of an online softmax; the time attention of a tile's tracks as ONE block-diagonal unit per head), so
+    the outputs agree to bf16 rounding (a flipped rounding of one bf16 activation moves an output by ~1e-3 of its scale), not bit
+    for bit; the bits that only move WHERE partials are combined (16) stay bit-identical.  The bar against the reference is
+    test_updateformer_bf16_vs_reference / test_refine_window_bf16_vs_reference_autocast."""
     x = torch.randn(1, n, 12, 581, generator=torch.Generator().manual_seed(n)).to(DEV)
     outs = {}
     with _with_precision(model, "bf16"):
@@ -724,8 +728,12 @@ def test_updater_fused_attention_bit_identical(model, n):
         finally:
             model.fuse_attention = old
     assert bool(torch.isfinite(outs[0]).all())
-    for f in (1, 2, 4, 16, 23):
-        assert torch.equal(outs[f], outs[0]), f"fuse_attention={f}: max diff {(outs[f] - outs[0]).abs().max().item():.3e}"
+    assert torch.equal(outs[16], outs[0]), f"fuse_attention=16: max diff {(outs[16] - outs[0]).abs().max().item():.3e}"
+    for f in (1, 2, 4, 23):
+        rel = ((outs[f] - outs[0]).abs().max() / outs[0].abs().max()).item()
+        mean = ((outs[f] - outs[0]).abs().mean() / outs[0].abs().mean()).item()
+        print(f"n={n} fuse_attention={f}: max {rel:.2e} mean {mean:.2e}")
+        assert rel < 3e-2 and mean < 1e-2, (f, rel, mean)
 
 
 def test_single_point_streams_match_sequential(model):

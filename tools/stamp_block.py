@@ -67,7 +67,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 if lib is None:  # shipped library: time only
     ts = []
-    for rep in range(6):
+    for rep in range(int(os.environ.get("REPS", "6"))):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
@@ -75,7 +75,8 @@ if lib is None:  # shipped library: time only
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 20 * 1e3)
-    print(kind, "us per launch:", " ".join(f"{t:.1f}" for t in ts[1:]))
+    ts = ts[1:]
+    print(kind, f"us per launch: min {min(ts):.1f} median {sorted(ts)[len(ts) // 2]:.1f} |", " ".join(f"{t:.1f}" for t in ts[:8]))
     sys.exit(0)
 assert lib.mvt_debug_clear_stamps() == 0
 run()
