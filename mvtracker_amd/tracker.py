@@ -128,6 +128,7 @@ class MVTracker(nn.Module):
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
         self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
+        self.presearch = os.environ.get("MVT_PRESEARCH", "1") != "0"  # first searches of new tracks beside the first encoder block
         self.defer_encoder = os.environ.get("MVT_ENC_DEFER", "0") != "0"  # one block of later frames per window on the side stream (A/B: no gain at C3)
         self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
         self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
@@ -535,7 +536,7 @@ class MVTracker(nn.Module):
             hip.avgpool2(fv[lvl - 1][a:b], fv[lvl][a:b], (b - a) * V, h, w, self.latent_dim)
 
     @hip.guarded
-    def build_frame_store(self, rgbs, depths, intrs, extrs, t0=0, level0=None, t1=None):
+    def build_frame_store(self, rgbs, depths, intrs, extrs, t0=0, level0=None, t1=None, after_geometry=None):
         """Features and world-space points of every pyramid level, frame-major.
 
         rgbs (V,T,3,H,W), depths (V,T,1,H,W), intrs (V,T,3,3), extrs (V,T,3,4).  ``level0`` (T,V,H/4,W/4,C)
@@ -555,7 +556,6 @@ class MVTracker(nn.Module):
             fv.append(torch.empty(T, V, hs >> lvl, ws >> lvl, C, device=dev, dtype=sdt))
         for f_ in fv[(1 if level0 is not None else 0):]:
             f_[:t0].zero_()
-        self.fill_frame_features({"fvec": fv}, rgbs, t0, t1, level0)
         kinv = torch.empty(V * T, 9, device=dev)
         einv = torch.empty(V * T, 12, device=dev)
         hip.invert_cameras(intrs.reshape(V * T, 9), extrs.reshape(V * T, 12), kinv, einv, V * T)
@@ -583,7 +583,13 @@ class MVTracker(nn.Module):
             box.append(b)
             tgrid.append(g)
             gbox.append(gb)
-        return {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds, "box": box, "tile_grid": tgrid, "gbox": gbox}
+        store = {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds, "box": box, "tile_grid": tgrid, "gbox": gbox}
+        # geometry first (a handful of small kernels), features after: what only needs the point clouds -- the first, unseeded
+        # neighbour searches of new tracks -- can then run beside the encoder (``after_geometry``, see forward)
+        if after_geometry is not None:
+            after_geometry(store)
+        self.fill_frame_features(store, rgbs, t0, t1, level0)
+        return store
 
     def _nseg(self, P: int, K: int) -> int:
         """Segments (runs of 64-point tiles) scanned by different waves; none may be empty."""
@@ -811,7 +817,7 @@ class MVTracker(nn.Module):
         mask_vis = torch.stack([track_mask.float(), vis_init.float()], dim=2).contiguous()
         return self._refine(store, frame0, coords, ffeats, mask_vis, iters, nan_flag, trace)
 
-    def _refine(self, store, frame0, coords, ffeats, mask_vis, iters=4, nan_flag=None, trace=None, carry=None):
+    def _refine(self, store, frame0, coords, ffeats, mask_vis, iters=4, nan_flag=None, trace=None, carry=None, pre_idx=None):
         """The refinement loop (mvtracker.py:350-408) on prepared state: coords (n,S,3) and ffeats (n,S,C) are updated IN PLACE,
         mask_vis (n,S,2) = (track mask, initial visibility logit).  Returns ([coords per traced iteration ..., final], vis).
         ``carry`` = (neighbour indices (L,n_prev,S,K) of the previous window's last iteration, p0): the first p0 tracks continue
@@ -834,7 +840,10 @@ class MVTracker(nn.Module):
         nsegs = [self._nseg(store["P"][lvl], K) for lvl in range(L)]
         keys = [torch.empty(n * S * nsegs[lvl] * K, device=dev, dtype=torch.int64) for lvl in range(L)]
         # neighbour indices of every level: returned for tracing AND used to seed (prune) the next exact scan
-        idx = torch.empty(L, n, S, K, device=dev, dtype=torch.int32)
+        # (``pre_idx``: the same buffer with the NEW tracks' rows of the first iteration already searched -- forward runs those
+        #  unseeded searches, which depend on the query points and the geometry only, on the second stream beside the encoder)
+        idx = pre_idx if pre_idx is not None else torch.empty(L, n, S, K, device=dev, dtype=torch.int32)
+        assert tuple(idx.shape) == (L, n, S, K)
         grid = [tuple(store["xyz"][lvl].shape[2:4]) for lvl in range(L)]  # per-view (h, w) of each level
         preds = []
         if trace is not None:  # the state every iteration's search / correlation starts from (teacher-forced parity checks)
@@ -865,7 +874,9 @@ class MVTracker(nn.Module):
                     else:
                         hip.knn_scan_levels(lv0, coords, n0, S, frame0, 1, T, K, seed_k=K)
                         hip.knn_merge_levels(lv0, n0, S, K)
-                if n0 < n and self.knn_one_launch and all(b is not None for b in store["box"]):
+                if n0 < n and pre_idx is not None:
+                    pass  # searched ahead of time
+                elif n0 < n and self.knn_one_launch and all(b is not None for b in store["box"]):
                     # new tracks: all four levels in ONE unseeded launch (every search starts from the farthest-corner bound of the
                     # nearest full tile) -- 262 us against four dependent coarse-to-fine launches of ~100 us each
                     m = n - n0
@@ -982,18 +993,59 @@ class MVTracker(nn.Module):
         windows = []
         pending = []  # (first frame, event): feature chunks being encoded on the side stream
         side_chunks = []  # first frames of the blocks the side stream has not been given yet
+        pre = {}  # window start -> (neighbour buffer with the new tracks' first search done, 1-NN keys per query-frame group)
+
+        def presearch(st):
+            """Everything of the call that needs the point clouds but no features: the first, UNSEEDED neighbour search of the tracks
+            that enter at each window (their coordinates are the query points, mvtracker.py:505-511) and the 1-NN scans of the
+            feature init (:607-645).  Issued on the second stream between the geometry and the encoder of the first window's frames,
+            so these searches (~0.4 ms at C3, latency-bound gathers) run beside the convolutions instead of after them."""
+            if dev.type != "cuda" or not self.presearch or not self.knn_one_launch or any(b is None for b in st["box"]):
+                return
+            K, L = self.corr_neighbors, self.corr_n_levels
+            side = self._side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                ww, q0 = w, 0
+                P0 = st["P"][0]
+                ns = self._nseg(P0, 1)
+                while ww < T - S // 2:
+                    q1 = int(np.searchsorted(qt_s, ww + S, side="left"))
+                    if q1 > q0:
+                        m = q1 - q0
+                        idxb = torch.empty(L, q1, S, K, device=dev, dtype=torch.int32)
+                        c0 = qxyz[q0:q1, None, :].expand(m, S, 3).contiguous()
+                        lv = [dict(xyz=st["xyz"][l], P=st["P"][l], seed_idx=None, box=st["box"][l], grid=st["tile_grid"][l],
+                                   idx_out=idxb[l][q0:], gbox=st["gbox"][l]) for l in range(L)]
+                        hip.knn_search_levels(lv, c0, m, S, ww, 1, T, K, seed_k=0)
+                        groups = []
+                        a = q0
+                        while a < q1:
+                            t = int(qt_s[a])
+                            b = min(int(np.searchsorted(qt_s, t, side="right")), q1)
+                            keys = torch.empty((b - a) * ns, device=dev, dtype=torch.int64)
+                            hip.knn_scan(st["xyz"][0], P0, qxyz[a:b], b - a, 1, t, 0, T, 1, ns, keys, box=st["box"][0], grid=st["tile_grid"][0])
+                            groups.append((a, b, t, keys))
+                            a = b
+                        pre[ww] = (idxb, groups, c0)
+                    ww += S // 2
+                    q0 = q1
+                ev = torch.cuda.Event()
+                ev.record(side)
+            pre["event"] = ev
+
         if w < T - S // 2:
             if frame_store is not None:
                 store = frame_store
                 pending = list(frame_store.get("pending", ()))  # (first frame, event) of feature blocks still in flight
             elif not self.overlap_encoder or max(w, 0) + S >= T or dev.type != "cuda":
-                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0))
+                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), after_geometry=presearch)
             else:
                 # The first window needs frames [w, w+S).  The remaining frames are encoded on a second HIP stream while
                 # the updater of the earlier windows runs: its kernels over the 64 virtual tracks fill a fraction of the
                 # CUs, the encoder's convolutions take the rest.
                 ready = max(w, 0) + S
-                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), t1=ready)
+                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), t1=ready, after_geometry=presearch)
                 side_chunks = list(range(ready, T, S // 2))  # first frames of the S/2-frame blocks still to encode
                 if not self.defer_encoder:
                     self._encode_on_side_stream(store, rgbs, side_chunks, pending)
@@ -1010,7 +1062,15 @@ class MVTracker(nn.Module):
                 # refined -- its convolutions fill the CUs the 64 virtual tracks' kernels leave idle -- instead of all blocks
                 # piling onto the first window (which then runs at half speed while the last windows run alone)
                 self._encode_on_side_stream(store, rgbs, [side_chunks.pop(0)], pending)
-            if p1 > p0:  # feature init: 1-NN in the fused level-0 cloud of the query frame (:607-645)
+            if "event" in pre:  # the searches issued ahead of time on the second stream
+                torch.cuda.current_stream(dev).wait_event(pre.pop("event"))
+            pre_w = pre.get(w)
+            if p1 > p0 and pre_w is not None:  # feature init from the 1-NN keys scanned ahead of time
+                P0 = store["P"][0]
+                ns = self._nseg(P0, 1)
+                for (a, b, t, keys) in pre_w[1]:
+                    hip.knn1_gather(store["fvec"][0], P0, C, keys, b - a, ns, t, feat_init[a:b])
+            elif p1 > p0:  # feature init: 1-NN in the fused level-0 cloud of the query frame (:607-645)
                 P0 = store["P"][0]
                 ns = self._nseg(P0, 1)
                 a = p0
@@ -1034,7 +1094,7 @@ class MVTracker(nn.Module):
                 wtrace = {}
                 trace.append(wtrace)
             preds, vis = self._refine(store, w, wc, wf, wm, iters=iters, nan_flag=nan_flag, trace=wtrace,
-                                      carry=(prev_idx, p0) if p0 > 0 else None)
+                                      carry=(prev_idx, p0) if p0 > 0 else None, pre_idx=pre_w[0] if pre_w is not None else None)
             prev_idx = self._last_idx
             coords = preds[-1]
             hip.window_store(coords, vis, order_d, p1, S, w, T, N, traj, vis_logit, vis_prob)  # :692-693, un-sorted (:710-711)

@@ -864,3 +864,23 @@ def test_forward_other_window_lengths(S, seed):
     ev = (m.last_vis_logits.cpu() - ro["vis_logits"]).abs().max().item()
     print(f"S={S} bf16: tracks rel err {et:.2e} (tol {tol_t:.2e}), vis logits {ev:.2e} (tol {tol_v:.2e})")
     assert et < max(tol_t, 1e-4) and ev < max(tol_v, 1e-3), (et, ev, tol_t, tol_v)
+
+
+@pytest.mark.parametrize("S,seed", [(8, 0), (8, 1), (16, 0), (16, 1)])
+def test_other_window_lengths_teacher_forced(S, seed):
+    """Window lengths 8 and 16 on ARBITRARY seeds (test_forward_other_window_lengths needs seeds without a near-tie in any
+    neighbour ranking for its end-to-end comparison): every iteration of every window -- the carry-over seeding with the slot
+    shift s -> s + S/2 included -- teacher-forced against the oracle on the device's own track state: kNN indices bit-exact,
+    correlation rows within 5e-5.  A near-tie swap therefore cannot hide (or be blamed for) a window-length-dependent error in the
+    search; the reference holds no fixture for S != 12, so the END-TO-END parity of other window lengths stays "unpinned"
+    (DESIGN.md section 2)."""
+    from mvtracker_amd.tracker import MVTracker
+    m = MVTracker(hidden_size=256, sliding_window_len=S).eval()
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV)
+    clip = synth.make_clip(seed, V=2, T=2 * S + S // 2, H=96, W=128, N=21, late_queries=True, query_frames=(1, S // 2 + 1))
+    for prec in ("fp32", "bf16"):
+        m.precision = prec
+        w = _check_forward_trace(m, args_of(clip, DEV), n_sample=21, iters=3)
+        print(f"S={S} seed={seed} {prec}: fcorr rows max abs err {w:.2e}")
