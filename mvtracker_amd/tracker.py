@@ -109,6 +109,8 @@ class MVTracker(nn.Module):
             _insert(self, key, self._init_tensor(key, shape))
         self._packed: Optional[dict] = None
         self._packed_sig = None
+        self._plist = None
+        self._slot_cache = {}
         # arithmetic of the matrix-core kernels (convs + linears); everything else is always fp32:
         #   "fp32"   v_mfma_f32_32x32x2_f32, exact fp32 FMA chains
         #   "bf16x3" split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi), fp32-grade results, ~5x the fp32 MFMA rate
@@ -227,7 +229,11 @@ class MVTracker(nn.Module):
         flags = (str(dev), self.precision, self.fuse_attention, self.fuse_input, self.composite_encoder, self._composite_updater_ok(),
                  self._composite_encoder_ok(), self.bf16_tokens, self.bf16_activations, self.fuse_blocks, self.mfma_attention, self.fuse_norm,
                  self.depth, self.hidden)
-        return flags + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        # (the Parameter objects are fixed at construction -- load_state_dict / .to() change their data in place -- so the module
+        #  tree is walked once: nn.Module.parameters() costs ~0.8 ms per walk, and this runs several times per call)
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        return flags + tuple(p._version for p in self._plist) + tuple(p.data_ptr() for p in self._plist)
 
     def _pack(self, dev) -> dict:
         sig = self._signature(dev)
@@ -479,7 +485,7 @@ class MVTracker(nn.Module):
             self._conv(pk, "fnet.conv3", y, n, hs, ws, 2 * C, C, 1, 1, 0, out=out_rows, ldo=C)
 
     @hip.guarded
-    def encode_images(self, rgbs, i0, i1, out, images_per_chunk=16):
+    def encode_images(self, rgbs, i0, i1, out, images_per_chunk=16, after_first_chunk=None):
         """Encode images [i0, i1) of rgbs (V,T,3,H,W) in [0,255] -- images numbered frame-major, t * V + v, the order of the
         frame store -- into ``out`` (>= i1 images, H/4, W/4, C): image i lands in out[i]."""
         V, T, _, H, W = rgbs.shape
@@ -489,8 +495,13 @@ class MVTracker(nn.Module):
             x4 = torch.empty(n, H, W, 4, device=rgbs.device)
             hip.rgb_images_to_nhwc4(rgbs, x4, V, T, H, W, a, n)
             self._encode(pk, x4, n, H, W, out[a:a + n])
+            if after_first_chunk is not None:  # (host-side hook: the GPU has work queued now, see MVTracker.forward)
+                after_first_chunk()
+                after_first_chunk = None
+        if after_first_chunk is not None:
+            after_first_chunk()
 
-    def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16, out=None, out_t0=0):
+    def encode_frames(self, rgbs, t0=0, t1=None, images_per_chunk=16, out=None, out_t0=0, after_first_chunk=None):
         """rgbs (V,T,3,H,W) in [0,255] -> level-0 features (T,V,H/4,W/4,C); frames outside [t0,t1) are left zero
         (or untouched when the result goes into ``out``, whose first row is frame ``out_t0``)."""
         V, T, _, H, W = rgbs.shape
@@ -499,7 +510,8 @@ class MVTracker(nn.Module):
         F0 = out if out is not None else torch.zeros(T, V, hs, ws, self.latent_dim, device=rgbs.device, dtype=self.store_dtype())
         flat = F0.view(-1, hs, ws, self.latent_dim)
         # (whole frames per chunk, as before: the chunk boundaries do not change any result, only the launch shapes)
-        self.encode_images(rgbs, t0 * V, t1 * V, _Shifted(flat, out_t0 * V), images_per_chunk=max(1, images_per_chunk // V) * V)
+        self.encode_images(rgbs, t0 * V, t1 * V, _Shifted(flat, out_t0 * V), images_per_chunk=max(1, images_per_chunk // V) * V,
+                           after_first_chunk=after_first_chunk)
         return F0
 
     # ------------------------------------------------------------------ frame store (model_utils.py:420-482)
@@ -524,13 +536,16 @@ class MVTracker(nn.Module):
                 pending.append((a, ev))
 
     @hip.guarded
-    def fill_frame_features(self, store, rgbs, a, b, level0=None):
+    def fill_frame_features(self, store, rgbs, a, b, level0=None, after_first_chunk=None):
         """Encode frames [a, b) into the store's feature pyramid (everything else in the store is geometry)."""
         V, T, _, H, W = rgbs.shape
         hs, ws = H // self.stride, W // self.stride
         fv = store["fvec"]
         if level0 is None:
-            self.encode_frames(rgbs, a, b, images_per_chunk=self.encoder_chunk_images or max(16, V * (self.S // 2)), out=fv[0])
+            self.encode_frames(rgbs, a, b, images_per_chunk=self.encoder_chunk_images or max(16, V * (self.S // 2)), out=fv[0],
+                               after_first_chunk=after_first_chunk)
+        elif after_first_chunk is not None:
+            after_first_chunk()
         for lvl in range(1, self.corr_n_levels):
             h, w = hs >> (lvl - 1), ws >> (lvl - 1)
             hip.avgpool2(fv[lvl - 1][a:b], fv[lvl][a:b], (b - a) * V, h, w, self.latent_dim)
@@ -585,10 +600,13 @@ class MVTracker(nn.Module):
             gbox.append(gb)
         store = {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds, "box": box, "tile_grid": tgrid, "gbox": gbox}
         # geometry first (a handful of small kernels), features after: what only needs the point clouds -- the first, unseeded
-        # neighbour searches of new tracks -- can then run beside the encoder (``after_geometry``, see forward)
-        if after_geometry is not None:
-            after_geometry(store)
-        self.fill_frame_features(store, rgbs, t0, t1, level0)
+        # neighbour searches of new tracks -- can then run beside the encoder.  ``after_geometry(store)`` is called on the host as
+        # soon as the FIRST encoder chunk has been enqueued (the GPU is busy from then on); work it issues on another stream
+        # orders itself after store["geo_event"], not after the encoder.
+        if dev.type == "cuda":
+            store["geo_event"] = torch.cuda.Event()
+            store["geo_event"].record(torch.cuda.current_stream(dev))
+        self.fill_frame_features(store, rgbs, t0, t1, level0, after_first_chunk=(lambda: after_geometry(store)) if after_geometry else None)
         return store
 
     def _nseg(self, P: int, K: int) -> int:
@@ -866,7 +884,11 @@ class MVTracker(nn.Module):
                     # every frame's cloud (same pixel grid), i.e. an exact upper bound of the K-th distance, and a tight one; all
                     # four levels in one seeded launch instead of four coarse-to-fine scans.  Exactness is unaffected.
                     prev_idx, n0 = carry
-                    slot = torch.tensor([min(s_ + S // 2, S - 1) for s_ in range(S)], device=dev)
+                    # (cached on the device: building it from a Python list is a synchronous host-to-device copy -- the host,
+                    #  several milliseconds ahead of the GPU, would stall here until the stream drains)
+                    slot = self._slot_cache.get((S, dev))
+                    if slot is None:
+                        slot = self._slot_cache[(S, dev)] = torch.tensor([min(s_ + S // 2, S - 1) for s_ in range(S)], device=dev)
                     seed_t = prev_idx[:, :n0].index_select(2, slot).contiguous()
                     lv0 = [dict(lv, keys=keys[l_][:n0 * S * nsegs[l_] * K], seed_idx=seed_t[l_], idx_out=idx[l_][:n0]) for l_, lv in enumerate(levels)]
                     if self.knn_one_launch:
@@ -979,15 +1001,22 @@ class MVTracker(nn.Module):
         qt = qt_dev.cpu().numpy()
         order = np.argsort(qt, kind="stable")  # mvtracker.py:514 (order among equal t is unobservable)
         qt_s = qt[order]
+        # (the two tiny host-to-device copies go first, while the GPU is idle anyway: from pageable memory they block the host until
+        #  the stream has drained, which after the first encoder chunk would be milliseconds)
         order_d = torch.from_numpy(order).to(dev)
-        qxyz = query_points[order_d, 1:].contiguous()  # (N,3), sorted by start frame
-
-        traj = torch.zeros(T, N, 3, device=dev)       # clip outputs in the caller's query order (window_store un-sorts)
-        vis_prob = torch.zeros(T, N, device=dev)
-        vis_logit = torch.zeros(T, N, device=dev)
-        feat_init = torch.zeros(N, C, device=dev)
-        nan_flag = torch.zeros(1, device=dev, dtype=torch.int32)
         qt_sd = torch.from_numpy(qt_s.astype(np.int32)).to(dev)
+        state = []
+
+        def make_state():
+            """Device-side bookkeeping of the call.  Created AFTER the first encoder chunk has been enqueued (see ``presearch``):
+            the GPU idles from the host sync above until the first kernels arrive, so nothing that can wait goes before them."""
+            if not state:
+                state.append(dict(
+                    qxyz=query_points[order_d, 1:].contiguous(),  # (N,3), sorted by start frame
+                    traj=torch.zeros(T, N, 3, device=dev),        # clip outputs in the caller's query order (window_store un-sorts)
+                    vis_prob=torch.zeros(T, N, device=dev), vis_logit=torch.zeros(T, N, device=dev),
+                    feat_init=torch.zeros(N, C, device=dev), nan_flag=torch.zeros(1, device=dev, dtype=torch.int32)))
+            return state[0]
 
         w = int(qt_s.min())
         windows = []
@@ -1000,11 +1029,12 @@ class MVTracker(nn.Module):
             that enter at each window (their coordinates are the query points, mvtracker.py:505-511) and the 1-NN scans of the
             feature init (:607-645).  Issued on the second stream between the geometry and the encoder of the first window's frames,
             so these searches (~0.4 ms at C3, latency-bound gathers) run beside the convolutions instead of after them."""
+            qxyz = make_state()["qxyz"]
             if dev.type != "cuda" or not self.presearch or not self.knn_one_launch or any(b is None for b in st["box"]):
                 return
             K, L = self.corr_neighbors, self.corr_n_levels
             side = self._side_stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
+            side.wait_stream(torch.cuda.current_stream(dev)) if "geo_event" not in st else side.wait_event(st["geo_event"])
             with torch.cuda.stream(side):
                 ww, q0 = w, 0
                 P0 = st["P"][0]
@@ -1050,6 +1080,9 @@ class MVTracker(nn.Module):
                 if not self.defer_encoder:
                     self._encode_on_side_stream(store, rgbs, side_chunks, pending)
                     side_chunks = []
+        sd_ = make_state()
+        qxyz, traj, vis_prob, vis_logit = sd_["qxyz"], sd_["traj"], sd_["vis_prob"], sd_["vis_logit"]
+        feat_init, nan_flag = sd_["feat_init"], sd_["nan_flag"]
         p0 = 0
         coords = vis = prev_idx = None
         while w < T - S // 2:  # mvtracker.py:537
