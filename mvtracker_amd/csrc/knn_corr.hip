@@ -653,7 +653,25 @@ __global__ __launch_bounds__(256) void window_corr_levels_kernel(WinLevels lv, c
   __shared__ float dots[4][16 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int level = blockIdx.y;
-  const long long row = (long long)blockIdx.x * 4 + wave;  // bs * N + n
+  // XCD-aware unit order (cdna_hip_programming.md T1): consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
+  // 4 MiB L2.  All windows of one frame read the same map (4 MiB at level 0 in bf16), so every XCD is given WHOLE frames -- frame f
+  // to XCD f % 8 -- and only the S % 8 leftover frames are shared, each by 8 / (S % 8) XCDs.  In plain row order every XCD touched
+  // every frame's map and the memory side saw 5x the unique bytes (profiles/r03_window_corr.json).
+  long long wg = blockIdx.x;
+  {
+    const long long per_frame = N / 4, total = (long long)BS * per_frame;
+    const int rem = BS % 8;
+    if (N % 4 == 0 && gridDim.x == total && total % 8 == 0 && (rem * per_frame) % 8 == 0) {
+      const long long xcd = wg % 8, j = wg / 8, whole = (long long)(BS / 8) * per_frame;
+      if (j < whole) {
+        wg = ((j / per_frame) * 8 + xcd) * per_frame + j % per_frame;
+      } else {
+        const long long u = xcd * (rem * per_frame / 8) + (j - whole);
+        wg = ((long long)(BS - rem) + u / per_frame) * per_frame + u % per_frame;
+      }
+    }
+  }
+  const long long row = wg * 4 + wave;  // bs * N + n
   if (row >= (long long)BS * N) return;
   const long long bs = row / N;
   const int h = lv.h[level], w = lv.w[level];

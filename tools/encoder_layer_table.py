@@ -9,8 +9,14 @@ from collections import defaultdict
 
 db = sys.argv[1]
 n_img, H = 24, 512
-c = sqlite3.connect(db).cursor()
-rows = list(c.execute("select name, grid_x, end-start from kernels where name like '%conv_rows_bf16%' or name like '%stem7x7%' order by start"))
+if db.endswith(".csv"):  # rocprofv3 --kernel-trace --output-format csv
+    import csv
+    rows = [(r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for r in sorted(csv.DictReader(open(db)), key=lambda r: int(r["Start_Timestamp"]))
+            if "conv_rows_bf16" in r["Kernel_Name"] or "stem7x7" in r["Kernel_Name"]]
+else:
+    c = sqlite3.connect(db).cursor()
+    rows = list(c.execute("select name, grid_x, end-start from kernels where name like '%conv_rows_bf16%' or name like '%stem7x7%' order by start"))
 
 
 def fl(ho, cout, cin, k):
