@@ -15,6 +15,7 @@ dev = "cuda"
 a = [int(v) for v in sys.argv[1:9]] if len(sys.argv) >= 9 else [16, 256, 256, 64, 64, 3, 1, 1]
 n, H, W, Cin, Cout, k, s, p = a
 bf = len(sys.argv) > 9 and sys.argv[9] == "1"
+norm = not (len(sys.argv) > 10 and sys.argv[10] == "0")  # 10th argument 0: no normalise-on-load (conv2 reads materialised activations)
 stem = Cin == 4
 K = k * 32 if stem else k * k * Cin
 ld = (K + 63) // 64 * 64
@@ -34,7 +35,7 @@ ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=
 for it in range(6):
     if it == 1:
         ev0.record()
-    hip.conv2d_bf16(x, hi, None, b, out, n, H, W, Cin, Cout, k, k, s, p, Cout, in_stats=st if (k == 3 and s == 1) else None,
+    hip.conv2d_bf16(x, hi, None, b, out, n, H, W, Cin, Cout, k, k, s, p, Cout, in_stats=st if (k == 3 and s == 1 and norm) else None,
                     out_partial=part if slots else None)
 ev1.record()
 torch.cuda.synchronize()
