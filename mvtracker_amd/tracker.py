@@ -16,6 +16,7 @@ Differences from the reference, all result-preserving:
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 import math
 import os
@@ -130,6 +131,7 @@ class MVTracker(nn.Module):
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
         self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
+        self.encoder_streams = int(os.environ.get("MVT_ENC_STREAMS", "2"))  # 2: the chunks of an encoder call alternate between two streams
         self.presearch = os.environ.get("MVT_PRESEARCH", "1") != "0"  # first searches of new tracks beside the first encoder block
         self.defer_encoder = os.environ.get("MVT_ENC_DEFER", "0") != "0"  # one block of later frames per window on the side stream (A/B: no gain at C3)
         self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
@@ -489,15 +491,35 @@ class MVTracker(nn.Module):
         """Encode images [i0, i1) of rgbs (V,T,3,H,W) in [0,255] -- images numbered frame-major, t * V + v, the order of the
         frame store -- into ``out`` (>= i1 images, H/4, W/4, C): image i lands in out[i]."""
         V, T, _, H, W = rgbs.shape
-        pk = self._pack(rgbs.device)
-        for a in range(i0, i1, images_per_chunk):
+        dev = rgbs.device
+        pk = self._pack(dev)
+        starts = list(range(i0, i1, images_per_chunk))
+        # MVT_ENC_STREAMS=2: the chunks of one call alternate between the caller's stream and a helper stream, so that the small
+        # layers of one chunk (layer 3 / 4 and the 1x1 convolutions fill a fraction of the chip) run beside the big layers of the other
+        two = self.encoder_streams == 2 and dev.type == "cuda" and len(starts) > 1
+        cur = torch.cuda.current_stream(dev) if two else None
+        helper = self._helper_stream(dev) if two else None
+        if two:
+            helper.wait_stream(cur)
+        joins = []
+        for ci, a in enumerate(starts):
             n = min(images_per_chunk, i1 - a)
-            x4 = torch.empty(n, H, W, 4, device=rgbs.device)
-            hip.rgb_images_to_nhwc4(rgbs, x4, V, T, H, W, a, n)
-            self._encode(pk, x4, n, H, W, out[a:a + n])
+            on_helper = two and ci % 2 == 1
+            ctx = torch.cuda.stream(helper) if on_helper else contextlib.nullcontext()
+            with ctx:
+                x4 = torch.empty(n, H, W, 4, device=dev)
+                hip.rgb_images_to_nhwc4(rgbs, x4, V, T, H, W, a, n)
+                self._encode(pk, x4, n, H, W, out[a:a + n])
+                if on_helper:
+                    ev = torch.cuda.Event()
+                    ev.record(helper)
+                    joins.append(ev)
+                    x4.record_stream(helper)
             if after_first_chunk is not None:  # (host-side hook: the GPU has work queued now, see MVTracker.forward)
                 after_first_chunk()
                 after_first_chunk = None
+        for ev in joins:
+            cur.wait_event(ev)
         if after_first_chunk is not None:
             after_first_chunk()
 
@@ -515,6 +537,12 @@ class MVTracker(nn.Module):
         return F0
 
     # ------------------------------------------------------------------ frame store (model_utils.py:420-482)
+    def _helper_stream(self, dev):
+        key = ("helper", dev.type, dev.index)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
     def _side_stream(self, dev):
         key = (dev.type, dev.index)
         if key not in self._side:
