@@ -554,13 +554,17 @@ class MVTracker(nn.Module):
         caller's stream so far); ``pending`` receives (first frame, event) per block."""
         dev = rgbs.device
         T, S = rgbs.shape[1], self.S
-        side = self._side_stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for a in firsts:
+        # (the later blocks stay on ONE stream, in order: alternating them between two streams as encode_images does for the chunks
+        #  of the first block measured +0.5 ms -- beside the updater their concurrency only adds contention)
+        streams = [self._side_stream(dev)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        for i, a in enumerate(firsts):
+            st = streams[i % len(streams)]
+            with torch.cuda.stream(st):
                 self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
                 ev = torch.cuda.Event()
-                ev.record(side)
+                ev.record(st)
                 pending.append((a, ev))
 
     @hip.guarded
