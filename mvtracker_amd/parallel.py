@@ -28,7 +28,11 @@ class ShardedTracker:
     def __init__(self, model, group: Optional["dist.ProcessGroup"] = None):
         self.model = model
         self.group = group
-        self.staged = os.environ.get("MVT_GATHER_STAGED", "0") != "0"  # stage the local share instead of the in-place all-gather
+        # The exchange stages this rank's share (a copy of 1 / world of the block: 50 MB of the 403 MB of a C3 clip at 8 GPUs, ~10 us)
+        # unless MVT_GATHER_INPLACE=1 asks for the aliasing in-place form.  The staged form is the DEFAULT because the multi-GPU
+        # path has never run on hardware at world > 1: an input that aliases the output is what
+        # ncclAllGather documents as in-place, but nothing here has been able to verify that torch + RCCL accept it.
+        self.staged = os.environ.get("MVT_GATHER_INPLACE", "0") == "0"
         self.last_store = None  # the frame store of the last call (tests compare it with a single-rank encode)
 
     def _world(self):
@@ -54,10 +58,9 @@ class ShardedTracker:
         """``out`` = world equal chunks along dim 0; this rank's chunk already holds its contribution.
 
         Which form runs is decided identically on every rank BEFORE the collective (a per-rank try / except around a collective
-        can leave ranks in different code paths): the in-place form -- the input aliases this rank's slot of the output, the
-        layout ncclAllGather documents as in-place (sendbuff == recvbuff + rank * sendcount) -- unless ``MVT_GATHER_STAGED=1``
-        asks for a staged copy of the local share (an A/B switch for a first multi-GPU bring-up; the same on all ranks because
-        the launcher exports one environment)."""
+        can leave ranks in different code paths): a staged copy of the local share by default, or -- ``MVT_GATHER_INPLACE=1``, the
+        same on all ranks because the launcher exports one environment -- the in-place form, where the input aliases this rank's
+        slot of the output, the layout ncclAllGather documents as in-place (sendbuff == recvbuff + rank * sendcount)."""
         per = out.shape[0] // world
         mine = out[rank * per:(rank + 1) * per]
         src = mine.clone() if self.staged else mine

@@ -1037,6 +1037,9 @@ class MVTracker(nn.Module):
         #  the stream has drained, which after the first encoder chunk would be milliseconds)
         order_d = torch.from_numpy(order).to(dev)
         qt_sd = torch.from_numpy(qt_s.astype(np.int32)).to(dev)
+        # (N,3) query points sorted by start frame -- enqueued HERE, ahead of the geometry: the searches issued on the second stream
+        # order themselves after the geometry event only, and they read these rows)
+        qxyz = query_points[order_d, 1:].contiguous()
         state = []
 
         def make_state():
@@ -1044,7 +1047,6 @@ class MVTracker(nn.Module):
             the GPU idles from the host sync above until the first kernels arrive, so nothing that can wait goes before them."""
             if not state:
                 state.append(dict(
-                    qxyz=query_points[order_d, 1:].contiguous(),  # (N,3), sorted by start frame
                     traj=torch.zeros(T, N, 3, device=dev),        # clip outputs in the caller's query order (window_store un-sorts)
                     vis_prob=torch.zeros(T, N, device=dev), vis_logit=torch.zeros(T, N, device=dev),
                     feat_init=torch.zeros(N, C, device=dev), nan_flag=torch.zeros(1, device=dev, dtype=torch.int32)))
@@ -1061,7 +1063,7 @@ class MVTracker(nn.Module):
             that enter at each window (their coordinates are the query points, mvtracker.py:505-511) and the 1-NN scans of the
             feature init (:607-645).  Issued on the second stream between the geometry and the encoder of the first window's frames,
             so these searches (~0.4 ms at C3, latency-bound gathers) run beside the convolutions instead of after them."""
-            qxyz = make_state()["qxyz"]
+            make_state()
             if dev.type != "cuda" or not self.presearch or not self.knn_one_launch or any(b is None for b in st["box"]):
                 return
             K, L = self.corr_neighbors, self.corr_n_levels
@@ -1113,7 +1115,7 @@ class MVTracker(nn.Module):
                     self._encode_on_side_stream(store, rgbs, side_chunks, pending)
                     side_chunks = []
         sd_ = make_state()
-        qxyz, traj, vis_prob, vis_logit = sd_["qxyz"], sd_["traj"], sd_["vis_prob"], sd_["vis_logit"]
+        traj, vis_prob, vis_logit = sd_["traj"], sd_["vis_prob"], sd_["vis_logit"]
         feat_init, nan_flag = sd_["feat_init"], sd_["nan_flag"]
         p0 = 0
         coords = vis = prev_idx = None

@@ -26,8 +26,9 @@ CASES = {
     # 8 ranks (the node size), 1 view x 14 frames: block one = 12 images, 2 per rank -> ranks 6 and 7 EMPTY; block two = 2 images,
     # 1 per rank -> ranks 2..7 EMPTY: several ranks have empty shares in BOTH blocks; one query per rank
     "eight_ranks_empty_shares": (8, dict(seed=74, V=1, T=14, H=128, W=128, N=8), True),
-    # the staged form of the exchange (MVT_GATHER_STAGED=1), uneven shares + spill
-    "three_ranks_staged": (3, dict(seed=72, V=2, T=15, H=96, W=96, N=10, late_queries=True, query_frames=(2, 5)), "staged"),
+    # the in-place form of the exchange (MVT_GATHER_INPLACE=1: the input aliases its slot of the output), uneven shares + spill;
+    # every other case runs the default staged form
+    "three_ranks_inplace": (3, dict(seed=72, V=2, T=15, H=96, W=96, N=10, late_queries=True, query_frames=(2, 5)), "inplace"),
 }
 
 
@@ -37,8 +38,8 @@ def _worker(rank, world, port, out_path, case):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2 if world <= 4 else 1)
-    if CASES[case][2] == "staged":
-        os.environ["MVT_GATHER_STAGED"] = "1"
+    if CASES[case][2] == "inplace":
+        os.environ["MVT_GATHER_INPLACE"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import hip_mock
     from mvtracker_amd import hip, synth
@@ -58,7 +59,7 @@ def _worker(rank, world, port, out_path, case):
     clip = synth.make_clip(**kw)
     a = [torch.from_numpy(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
     st = ShardedTracker(m)
-    assert st.staged == (overlap == "staged")
+    assert st.staged == (overlap != "inplace")
     res = st(*a, iters=2)
     # the exchanged level-0 store (image-granular shares, spill into the next block / the tail padding, no staging copy) must
     # equal a single-rank encode of the same frames, image for image, on EVERY rank
