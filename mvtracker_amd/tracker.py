@@ -1068,7 +1068,8 @@ class MVTracker(nn.Module):
                 return
             K, L = self.corr_neighbors, self.corr_n_levels
             side = self._side_stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev)) if "geo_event" not in st else side.wait_event(st["geo_event"])
+            main_s = torch.cuda.current_stream(dev)
+            side.wait_stream(main_s) if "geo_event" not in st else side.wait_event(st["geo_event"])
             with torch.cuda.stream(side):
                 ww, q0 = w, 0
                 P0 = st["P"][0]
@@ -1090,7 +1091,9 @@ class MVTracker(nn.Module):
                             keys = torch.empty((b - a) * ns, device=dev, dtype=torch.int64)
                             hip.knn_scan(st["xyz"][0], P0, qxyz[a:b], b - a, 1, t, 0, T, 1, ns, keys, box=st["box"][0], grid=st["tile_grid"][0])
                             groups.append((a, b, t, keys))
+                            keys.record_stream(main_s)  # (allocated under the second stream, consumed on the caller's)
                             a = b
+                        idxb.record_stream(main_s)
                         pre[ww] = (idxb, groups, c0)
                     ww += S // 2
                     q0 = q1
