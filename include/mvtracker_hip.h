@@ -334,6 +334,14 @@ int mvt_knn_search_levels(int levels, const mvt_knn_level* lv, const float* coor
 int mvt_corr_gather_dot(int levels, const float* const* xyz, const void* const* fvec, int fvec_bf16, const long long* P,
                         const int* const* idx, int C, const float* targets, const float* coords, int N, int S,
                         int frame0, int frame_step, int T, int K, float* out, int ldo, int o_off, void* stream);
+/* The same operator with the reference's non-default correlation options (mvtracker.py:130-149, 832-846): `groups` grouped dots per
+ * neighbour (each over C / groups channels, / sqrt(C / groups); a power of two dividing the lanes of a feature row), the neighbour
+ * offset (add_offset) and / or the neighbour's coordinates (add_xyz) appended: OW = groups + 3 add_offset + 3 add_xyz values per
+ * neighbour at out[(n*S+s)*ldo + o_off + (l*K + k)*OW ...]. */
+int mvt_corr_gather_dot_opts(int levels, const float* const* xyz, const void* const* fvec, int fvec_bf16, const long long* P,
+                             const int* const* idx, int C, const float* targets, const float* coords, int N, int S, int frame0,
+                             int frame_step, int T, int K, int groups, int add_offset, int add_xyz, float* out, int ldo, int o_off,
+                             void* stream);
 /* 1-NN feature init: feat_out[n][C] (fp32) = fvec[frame][idx] with idx from keys [n][1][nseg][1]
  * (mvtracker.py:640-643); idx_out optional.  fvec_bf16: bf16 feature rows. */
 int mvt_knn1_gather(const void* fvec, int fvec_bf16, long long P, int C, const unsigned long long* keys, int n, int nseg,

@@ -563,6 +563,86 @@ __global__ __launch_bounds__(256) void corr_gather_dot_kernel(CorrLevels lv, con
   }
 }
 
+// The same operator with the reference's non-default options (mvtracker.py:832-846): ``groups`` grouped dots per neighbour (each over
+// C / groups channels, / sqrt(C / groups)), the neighbour offset and / or the neighbour's own coordinates appended -- OW = groups +
+// 3 * add_offset + 3 * add_xyz outputs per neighbour.  Same loads as the shipped-layout kernel above; the group sums stop the shuffle
+// reduction at the group's lanes and the group leaders store their value themselves (4-byte stores: a generality path, not the
+// benchmarked one).
+template <int LPR, int BF>
+__global__ __launch_bounds__(256) void corr_gather_dot_opts_kernel(CorrLevels lv, const float* __restrict__ targets,
+                                                                   const float* __restrict__ coords, int N, int S, int frame0,
+                                                                   int frame_step, int T, int K, float* __restrict__ out, int ldo, int o_off,
+                                                                   int G, int add_offset, int add_xyz) {
+  constexpr int EPL = BF ? 8 : 4;
+  constexpr int C = EPL * LPR;
+  constexpr int RPL = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int level = blockIdx.y;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // n * S + s
+  if (row >= (long long)N * S) return;
+  const int s = (int)(row % S);
+  int frame = frame0 + s * frame_step;
+  frame = frame < T - 1 ? frame : T - 1;
+  const long long P = lv.P[level];
+  const float* __restrict__ xyz = lv.xyz[level];
+  const float* __restrict__ fvec = lv.fvec[level];
+  unsigned idx = (unsigned)lv.idx[level][row * K + (lane < K ? lane : 0)];
+  if ((long long)idx >= P) idx = (unsigned)(P - 1);
+  const int sub = lane / LPR, cq = lane % LPR;
+  f32x4 tg[EPL / 4];
+#pragma unroll
+  for (int e = 0; e < EPL / 4; ++e) tg[e] = *reinterpret_cast<const f32x4*>(targets + row * C + cq * EPL + 4 * e);
+  const long long fbase = (long long)frame * P * C + cq * EPL;
+  constexpr int MAXJ = (16 + RPL - 1) / RPL;
+  const int OW = G + 3 * add_offset + 3 * add_xyz;
+  const int lpg = LPR / G;  // lanes per group
+  const float scale = sqrtf((float)(C / G));
+  float* orow = out + row * ldo + o_off + (long long)level * K * OW;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int k = j * RPL + sub;
+    const unsigned ik = __shfl(idx, k < K ? k : 0, 64);
+    f32x4 f0, f1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (BF) {
+      const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(fvec) + fbase + (long long)ik * C);
+      f0 = (f32x4){__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u)};
+      f1 = (f32x4){__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xFFFF0000u), __uint_as_float(w.w << 16), __uint_as_float(w.w & 0xFFFF0000u)};
+    } else {
+      f0 = *reinterpret_cast<const f32x4*>(fvec + fbase + (long long)ik * C);
+    }
+    float d = tg[0][0] * f0[0];
+    d = fmaf(tg[0][1], f0[1], d);
+    d = fmaf(tg[0][2], f0[2], d);
+    d = fmaf(tg[0][3], f0[3], d);
+    if (BF) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d = fmaf(tg[EPL / 4 - 1][e], f1[e], d);
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) {
+      const float other = __shfl_xor(d, o, 64);
+      if (o < lpg) d += other;  // (wave-uniform: the reduction stops at the group's lanes)
+    }
+    if (k < K && cq % lpg == 0) orow[k * OW + cq / lpg] = d / scale;
+  }
+  if (lane < K && (add_offset || add_xyz)) {
+    const f32x4 nx = *reinterpret_cast<const f32x4*>(xyz + ((long long)frame * P + idx) * 4);
+    const float* cw = coords + row * 3;
+    float* o = orow + lane * OW + G;
+    if (add_offset) {
+      o[0] = nx[0] - cw[0];
+      o[1] = nx[1] - cw[1];
+      o[2] = nx[2] - cw[2];
+      o += 3;
+    }
+    if (add_xyz) {
+      o[0] = nx[0];
+      o[1] = nx[1];
+      o[2] = nx[2];
+    }
+  }
+}
+
 template <int BF>
 __global__ __launch_bounds__(256) void knn1_gather_kernel(const float* __restrict__ fvec, long long P, int C,
                                                           const unsigned long long* __restrict__ keys, int n, int nseg, int frame,
@@ -994,6 +1074,50 @@ extern "C" int mvt_window_corr_levels(int levels, const void* const* fmaps, int 
   hipLaunchKernelGGL((window_corr_levels_kernel<LPR, BF>), grid, dim3(256), 0, mvt_stream(stream), lv, targets, coords, out, BS, N, radius, \
                      ldo, o_off)
   if (fmap_bf16) {
+    switch (C) {
+      case 32: LAUNCH(4, 1); break;
+      case 64: LAUNCH(8, 1); break;
+      case 128: LAUNCH(16, 1); break;
+      case 256: LAUNCH(32, 1); break;
+      default: return MVT_ERR_ARG;
+    }
+  } else {
+    switch (C) {
+      case 32: LAUNCH(8, 0); break;
+      case 64: LAUNCH(16, 0); break;
+      case 128: LAUNCH(32, 0); break;
+      case 256: LAUNCH(64, 0); break;
+      default: return MVT_ERR_ARG;
+    }
+  }
+#undef LAUNCH
+  return mvt_launch_status();
+}
+
+extern "C" int mvt_corr_gather_dot_opts(int levels, const float* const* xyz, const void* const* fvec, int fvec_bf16, const long long* P,
+                                        const int* const* idx, int C, const float* targets, const float* coords, int N, int S, int frame0,
+                                        int frame_step, int T, int K, int groups, int add_offset, int add_xyz, float* out, int ldo, int o_off,
+                                        void* stream) {
+  MVT_REQUIRE(levels >= 1 && levels <= 8 && xyz && fvec && P && idx && targets && coords && out);
+  MVT_REQUIRE((fvec_bf16 == 0 || fvec_bf16 == 1) && (add_offset == 0 || add_offset == 1) && (add_xyz == 0 || add_xyz == 1));
+  MVT_REQUIRE(N > 0 && S > 0 && T > 0 && frame0 >= 0 && frame0 < T && frame_step >= 0 && K >= 1 && K <= 16);
+  const int lpr = fvec_bf16 ? C / 8 : C / 4;  // lanes per feature row
+  MVT_REQUIRE(groups >= 1 && (groups & (groups - 1)) == 0 && lpr >= 1 && groups <= lpr && lpr % groups == 0);
+  const int OW = groups + 3 * add_offset + 3 * add_xyz;
+  MVT_REQUIRE(o_off >= 0 && ldo >= o_off + levels * K * OW);
+  CorrLevels lv{};
+  for (int l = 0; l < levels; ++l) {
+    MVT_REQUIRE(xyz[l] && fvec[l] && idx[l] && P[l] >= K && P[l] < (1LL << 31));
+    lv.xyz[l] = xyz[l];
+    lv.fvec[l] = (const float*)fvec[l];
+    lv.idx[l] = idx[l];
+    lv.P[l] = P[l];
+  }
+  const dim3 grid((unsigned)mvt_cdiv((long long)N * S, 4), (unsigned)levels);
+#define LAUNCH(LPR, BF)                                                                                                                   \
+  hipLaunchKernelGGL((corr_gather_dot_opts_kernel<LPR, BF>), grid, dim3(256), 0, mvt_stream(stream), lv, (const float*)targets, coords, N, S, \
+                     frame0, frame_step, T, K, out, ldo, o_off, groups, add_offset, add_xyz)
+  if (fvec_bf16) {
     switch (C) {
       case 32: LAUNCH(4, 1); break;
       case 64: LAUNCH(8, 1); break;

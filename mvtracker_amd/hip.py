@@ -64,6 +64,7 @@ SIGNATURES = {
     "mvt_tile_group_aabb": [P, LL, I, P, P],
     "mvt_knn_merge_levels": [I, P, I, I, I, P],
     "mvt_corr_gather_dot": [I, P, P, I, P, P, I, P, P, I, I, I, I, I, I, P, I, I, P],
+    "mvt_corr_gather_dot_opts": [I, P, P, I, P, P, I, P, P, I, I, I, I, I, I, I, I, I, P, I, I, P],
     "mvt_knn1_gather": [P, I, LL, I, P, I, I, I, P, P, P],
     "mvt_window_corr": [P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "mvt_window_corr_levels": [I, P, I, P, P, P, P, P, I, I, I, I, I, I, P],
@@ -406,6 +407,18 @@ def corr_gather_dot(xyz_l, fvec_l, P_l, idx_l, Cc, targets, coords, N, S, frame0
     _call("mvt_corr_gather_dot", n, pa(*[_ptr(t) for t in xyz_l]), pa(*[_ptr(t) for t in fvec_l]), 1 if bf else 0, (C.c_longlong * n)(*P_l),
           pa(*[_ptr(t) for t in idx_l]), Cc, _ptr(targets), _ptr(coords), N, S, frame0, frame_step, T, K, _ptr(out), ldo, o_off,
           _stream())
+
+
+def corr_gather_dot_opts(xyz_l, fvec_l, P_l, idx_l, Cc, targets, coords, N, S, frame0, frame_step, T, K, groups, add_offset, add_xyz, out, ldo,
+                         o_off):
+    """``corr_gather_dot`` with the non-default correlation options: groups + 3 add_offset + 3 add_xyz values per neighbour."""
+    n = len(xyz_l)
+    pa = (C.c_void_p * n)
+    bf = fvec_l[0].dtype == torch.bfloat16
+    assert all((t.dtype == torch.bfloat16) == bf for t in fvec_l)
+    _call("mvt_corr_gather_dot_opts", n, pa(*[_ptr(t) for t in xyz_l]), pa(*[_ptr(t) for t in fvec_l]), 1 if bf else 0, (C.c_longlong * n)(*P_l),
+          pa(*[_ptr(t) for t in idx_l]), Cc, _ptr(targets), _ptr(coords), N, S, frame0, frame_step, T, K, groups, 1 if add_offset else 0,
+          1 if add_xyz else 0, _ptr(out), ldo, o_off, _stream())
 
 
 def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):

@@ -48,6 +48,14 @@ def _bilinear_sample_depth_multi(depths: torch.Tensor, v: torch.Tensor, t: torch
             + (x1 - x) * (y - y0) * flat[base + cy1 * W + cx0] + (x - x0) * (y - y0) * flat[base + cy1 * W + cx1])
 
 
+def get_uniformly_sampled_pts(size: int, num_frames: int, extent: Tuple[float, ...], device="cpu") -> torch.Tensor:
+    """(1, size, 3) rows (t, a, b): t uniform in [0, num_frames), a uniform in [0, extent[1]), b in [0, extent[0]) -- reference
+    evaluation_predictor_3dpt.py:417-429, the same draws in the same order (torch.randint, then torch.rand)."""
+    time_points = torch.randint(low=0, high=num_frames, size=(size, 1), device=device)
+    space_points = torch.rand(size, 2, device=device) * torch.tensor([extent[1], extent[0]], device=device)
+    return torch.cat((time_points, space_points), dim=1)[None]
+
+
 def points_on_a_grid(size: int, extent: Tuple[float, float], center=None, device="cpu") -> torch.Tensor:
     """(size*size, 2) pixel (x, y) grid with margin W/64 (reference model_utils.py:361-417)."""
     if size == 1:
@@ -146,8 +154,6 @@ class EvaluationPredictor(torch.nn.Module):
             raise NotImplementedError
         if self.sift_size > 0:
             raise NotImplementedError
-        if self.num_uniformly_sampled_pts > 0:
-            raise NotImplementedError("uniformly sampled support points draw from the global RNG upstream; not supported")
         hip.require_device(rgbs)
         dev = rgbs.device
         V, T = num_views, num_frames
@@ -182,6 +188,21 @@ class EvaluationPredictor(torch.nn.Module):
                 for v in range(V):
                     rows.append(self._support_rows(depths[0, v, t, 0], pix, kinv[v, t], einv[v, t], t))
             support = torch.cat(rows, 0)
+
+        if self.num_uniformly_sampled_pts > 0:  # :147-190
+            # Uniformly sampled support points: (t, y, x) rows from get_uniformly_sampled_pts -- the same two torch draws as the
+            # reference, from the global generator of the tensors' device -- lifted into the world through EVERY view's depth map
+            # (sample-major, then view), with the reference's argument order kept as it is: the column it calls y is scaled by the
+            # WIDTH and the one it calls x by the HEIGHT (:424-426), and out-of-map coordinates are clamped by the sampler.
+            sp = get_uniformly_sampled_pts(self.num_uniformly_sampled_pts, T, (height, width), device=dev)[0]
+            t_s, y_s, x_s = sp[:, 0].long(), sp[:, 1].float(), sp[:, 2].float()
+            vid = torch.arange(V, device=dev).repeat(sp.shape[0])
+            fid, xs, ys = t_s.repeat_interleave(V), x_s.repeat_interleave(V), y_s.repeat_interleave(V)
+            z = _bilinear_sample_depth_multi(depths[0, :, :, 0], vid, fid, xs, ys)
+            camm = torch.einsum("mij,mj->mi", kinv[vid, fid], torch.stack([xs, ys, torch.ones_like(xs)], 1)) * z[:, None]
+            ei = einv[vid, fid]
+            world = torch.einsum("mij,mj->mi", ei[:, :, :3], camm) + ei[:, :, 3]
+            support = torch.cat([support, torch.cat([fid[:, None].to(world.dtype), world], 1)], 0)
 
         nan_flags = []
         fwd = dict(intrs=intrs, extrs=extrs, iters=self.n_iters, save_debug_logs=save_debug_logs,

@@ -86,8 +86,9 @@ class MVTracker(nn.Module):
         if corr_filter_invalid_depth:
             raise NotImplementedError("corr_filter_invalid_depth=True gathers with mismatched indices upstream "
                                       "(mvtracker.py:820-829); only the default False is implemented")
-        if corr_n_groups != 1 or not corr_add_neighbor_offset or corr_add_neighbor_xyz:
-            raise NotImplementedError("only the shipped correlation layout (1 group, neighbour offsets) is implemented")
+        lanes = fmaps_dim // 8  # lanes of a bf16 feature row: the grouped dots stop their reduction at whole lanes
+        if corr_n_groups < 1 or corr_n_groups & (corr_n_groups - 1) or corr_n_groups > lanes:
+            raise NotImplementedError(f"corr_n_groups must be a power of two <= fmaps_dim / 8 = {lanes}")
         if not add_space_attn or time_depth != space_depth:
             raise NotImplementedError("only add_space_attn=True with time_depth == space_depth is implemented")
         if fmaps_dim not in (32, 64, 128, 256) or not (1 <= corr_neighbors <= 16) or stride != 4:
@@ -98,13 +99,18 @@ class MVTracker(nn.Module):
         self.flow_embed_dim = 64
         self.corr_n_levels = corr_n_levels
         self.corr_neighbors = corr_neighbors
+        # correlation features per neighbour (mvtracker.py:136-141): grouped dots, neighbour offset, neighbour coordinates
+        self.corr_n_groups = corr_n_groups
+        self.corr_add_neighbor_offset = bool(corr_add_neighbor_offset)
+        self.corr_add_neighbor_xyz = bool(corr_add_neighbor_xyz)
+        self.corr_width = corr_n_groups + 3 * int(self.corr_add_neighbor_offset) + 3 * int(self.corr_add_neighbor_xyz)
         self.num_heads = num_heads
         self.dim_head = 48
         self.hidden = hidden_size
         self.depth = time_depth
         self.nv = num_virtual_tracks
         self.use_flash_attention = use_flash_attention  # accepted for config compatibility; same math
-        self.updateformer_input_dim = (self.flow_embed_dim + 1) * 3 + corr_neighbors * corr_n_levels * 4 + fmaps_dim + 2
+        self.updateformer_input_dim = (self.flow_embed_dim + 1) * 3 + corr_neighbors * corr_n_levels * self.corr_width + fmaps_dim + 2
         self.out_dim = 3 + fmaps_dim
         for key, shape in self._shapes().items():
             _insert(self, key, self._init_tensor(key, shape))
@@ -878,7 +884,8 @@ class MVTracker(nn.Module):
         pk = self._pack(dev)
         D = self.updateformer_input_dim
         T = store["T"]
-        Fc = L * K * 4
+        Fc = L * K * self.corr_width
+        default_corr = self.corr_n_groups == 1 and self.corr_add_neighbor_offset and not self.corr_add_neighbor_xyz
         pos = torch.empty(n, D, device=dev)
         hip.pos_embed(coords, n, S, D, _round_up(D, 6), pos, pk["pos_omega"])
         fcorr = torch.empty(n, S, Fc, device=dev)
@@ -952,8 +959,13 @@ class MVTracker(nn.Module):
                         hip.knn_scan(store["xyz"][lvl], P, coords[n0:], m, S, frame0, 1, T, K, nsegs[lvl], kl, box=store["box"][lvl],
                                      grid=store["tile_grid"][lvl], **seed)
                         hip.knn_merge(kl, m, S, K, nsegs[lvl], P, idx[lvl][n0:])
-            hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0, 1,
-                                T, K, fcorr, Fc, 0)
+            if default_corr:
+                hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0,
+                                    1, T, K, fcorr, Fc, 0)
+            else:  # the reference's non-default correlation layouts (grouped dots, no offsets, neighbour coordinates)
+                hip.corr_gather_dot_opts(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S,
+                                         frame0, 1, T, K, self.corr_n_groups, self.corr_add_neighbor_offset, self.corr_add_neighbor_xyz,
+                                         fcorr, Fc, 0)
             if (trace is None and "updater_struct" in pk and self.fuse_head and self.fuse_input and self.fuse_tokens
                     and pk["updater_struct"].input_frag.w):
                 # everything after the correlation in ONE library call: token rows assembled inside the updater's first kernel,

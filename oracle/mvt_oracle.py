@@ -690,7 +690,7 @@ def _unproject(pix_xy: Tensor, z: Tensor, kinv: Tensor, einv: Tensor) -> Tensor:
 
 
 def predictor_prepare(rgbs, depths, query_points_3d, intrs, extrs, interp_shape=(384, 512), grid_size=5,
-                      n_grids_per_view=1):
+                      n_grids_per_view=1, uniform_pts=None):
     """Resize + support-grid synthesis of EvaluationPredictor.forward (evaluation_predictor_3dpt.py:59-120).
 
     Returns (rgbs, depths, intrs, support_points (1,M,4))."""
@@ -716,15 +716,28 @@ def predictor_prepare(rgbs, depths, query_points_3d, intrs, extrs, interp_shape=
                 world = _unproject(pix, z, kinv[:, v, t], einv[:, v, t])
                 pts.append(torch.cat([torch.ones_like(world[:, :, :1]) * t, world], dim=2))
         support = torch.cat([support, torch.cat(pts, dim=1)], dim=1)
+    if uniform_pts is not None:
+        # uniformly sampled support points (evaluation_predictor_3dpt.py:147-190); ``uniform_pts`` (n,3) = the rows of
+        # get_uniformly_sampled_pts (:417-429).  Column 1 is what the reference calls y, column 2 what it calls x (:156-158).
+        rows = []
+        for i in range(uniform_pts.shape[0]):
+            t = int(uniform_pts[i, 0].long())
+            x, y = uniform_pts[i, 2].float().reshape(1, 1), uniform_pts[i, 1].float().reshape(1, 1)
+            for v in range(V):
+                z = bilinear_sample2d(depths[0, v, t][None], x, y).permute(0, 2, 1)
+                world = _unproject(torch.stack([x, y], -1), z, kinv[:, v, t], einv[:, v, t])
+                rows.append(torch.cat([torch.ones_like(world[:, :, :1]) * t, world], dim=2))
+        if rows:
+            support = torch.cat([support, torch.cat(rows, dim=1)], dim=1)
     return rgbs, depths, intrs, support
 
 
 def predictor_forward(W, cfg, rgbs, depths, query_points_3d, intrs, extrs, interp_shape=(384, 512),
-                      visibility_threshold=0.5, grid_size=5, n_grids_per_view=1, n_iters=6, knn_mode="exact"):
+                      visibility_threshold=0.5, grid_size=5, n_grids_per_view=1, n_iters=6, knn_mode="exact", uniform_pts=None):
     """EvaluationPredictor.forward, joint mode (evaluation_predictor_3dpt.py:341-360, 410-414)."""
     n = query_points_3d.shape[1]
     rgbs, depths, intrs, support = predictor_prepare(rgbs, depths, query_points_3d, intrs, extrs, interp_shape,
-                                                     grid_size, n_grids_per_view)
+                                                     grid_size, n_grids_per_view, uniform_pts)
     q = torch.cat([query_points_3d, support], dim=1)
     res = tracker_forward(W, cfg, rgbs, depths, q, intrs, extrs, iters=n_iters, knn_mode=knn_mode)
     vis = res["vis_e"][:, :, :n]

@@ -360,6 +360,29 @@ def corr_gather_dot(xyz_l, fvec_l, P_l, idx_l, Cc, targets, coords, N, S, frame0
             o[:, s, :, 1:] = X[f][idx[:, s]][..., :3] - c[:, s, None]
 
 
+def corr_gather_dot_opts(xyz_l, fvec_l, P_l, idx_l, Cc, targets, coords, N, S, frame0, frame_step, T, K, groups, add_offset, add_xyz, out, ldo,
+                         o_off):
+    OW = groups + 3 * int(add_offset) + 3 * int(add_xyz)
+    tg = torch.as_strided(targets, (N, S, Cc), (S * Cc, Cc, 1))
+    c = torch.as_strided(coords, (N, S, 3), (S * 3, 3, 1))
+    for lvl, (xyz, fvec, Pn, idx_t) in enumerate(zip(xyz_l, fvec_l, P_l, idx_l)):
+        X = torch.as_strided(xyz, (T, Pn, 4), (Pn * 4, 4, 1))
+        Fv = torch.as_strided(fvec, (T, Pn, Cc), (Pn * Cc, Cc, 1))
+        idx = idx_t.reshape(N, S, K).long()
+        o = torch.as_strided(out, (N, S, K, OW), (S * ldo, ldo, OW, 1), out.storage_offset() + o_off + lvl * OW * K)
+        for s in range(S):
+            f = min(frame0 + s * frame_step, T - 1)
+            nf = Fv[f][idx[:, s]].float()
+            o[:, s, :, :groups] = torch.einsum("ngc,nkgc->nkg", tg[:, s].reshape(N, groups, -1), nf.reshape(N, K, groups, -1)) / math.sqrt(Cc / groups)
+            nx = X[f][idx[:, s]][..., :3]
+            j = groups
+            if add_offset:
+                o[:, s, :, j:j + 3] = nx - c[:, s, None]
+                j += 3
+            if add_xyz:
+                o[:, s, :, j:j + 3] = nx
+
+
 def knn1_gather(fvec, Pn, Cc, keys, n, nseg, frame, feat_out, idx_out=None):
     idx = keys.reshape(n, nseg).min(1).values & 0xFFFFFFFF
     Fv = torch.as_strided(fvec, (frame + 1, Pn, Cc), (Pn * Cc, Cc, 1))
@@ -476,7 +499,7 @@ def install(monkeypatch):
     from mvtracker_amd import hip
     me = sys.modules[__name__]
     for name in ("gemm conv2d split_bf16 gemm_bf16 conv2d_stat_slots conv2d_bf16 instnorm_finish_slots ln_gemm_bf16 pack_frag_bf16 block_fused_bf16 ln_proj_bf16 mlp_fused_bf16 rgb_to_nhwc4 rgb_images_to_nhwc4 resize_nearest instnorm_stats instnorm_apply resize_bilinear_ac concat_resize_bilinear_ac invert_cameras "
-                 "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_search_levels knn_search tile_group_aabb knn_merge_levels corr_gather_dot knn1_gather pos_embed token_assemble delta_split "
+                 "attention_ws_floats depth_subsample avgpool2 unproject tile_aabb knn_scan knn_merge knn_scan_levels knn_search_levels knn_search tile_group_aabb knn_merge_levels corr_gather_dot corr_gather_dot_opts knn1_gather pos_embed token_assemble delta_split "
                  "rowdot layernorm attention attention_bf16 broadcast_rows window_corr window_prepare window_store require_device").split():
         monkeypatch.setattr(hip, name, getattr(me, name))
     monkeypatch.setattr(hip, "COMPOSITE", False)  # the per-kernel sequencing is what these tests exercise

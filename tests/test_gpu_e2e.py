@@ -884,3 +884,68 @@ def test_other_window_lengths_teacher_forced(S, seed):
         m.precision = prec
         w = _check_forward_trace(m, args_of(clip, DEV), n_sample=21, iters=3)
         print(f"S={S} seed={seed} {prec}: fcorr rows max abs err {w:.2e}")
+
+
+def test_predictor_uniform_support_points_golden(model, golden, monkeypatch):
+    """EvaluationPredictor(num_uniformly_sampled_pts=6) against the reference-generated fixture: the draw of the reference (it
+    samples from the global torch generator of its device) is injected, the query rows the model receives -- queries, support grid,
+    the sampled points lifted through both views' depth maps, including samples the reference's swapped (height, width) scaling puts
+    outside the map -- and the tracks must match."""
+    from mvtracker_amd import predictor as P
+    g = golden("predictor_uniform_pts")
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=12, H=96, W=160, N=4)
+    a = args_of(clip, DEV)
+    monkeypatch.setattr(P, "get_uniformly_sampled_pts", lambda *args, device="cpu", **kw: T(g["sampled_pts"]).to(device)[None])
+    pred = P.EvaluationPredictor(model, interp_shape=None, grid_size=2, num_uniformly_sampled_pts=6, n_iters=2)
+    calls = []
+    orig = model.forward
+
+    def spy(*args, **kw):
+        calls.append(kw["query_points"].clone())
+        return orig(*args, **kw)
+
+    model.forward = spy
+    try:
+        r = pred(rgbs=a[0], depths=a[1], query_points_3d=a[2], intrs=a[3], extrs=a[4])
+    finally:
+        model.forward = orig
+    assert len(calls) == 1 and tuple(calls[0].shape) == g["model_query_points"].shape
+    assert np.abs(calls[0].cpu().numpy() - g["model_query_points"]).max() < 1e-4
+    ref = g["traj_e"]
+    assert np.abs(r["traj_e"].cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    assert np.abs(r["vis_e_as_prob"].cpu().numpy() - g["vis_e_as_prob"]).max() < 1e-3
+    # and the un-patched sampler: the reference's two draws, on the tensors' device
+    monkeypatch.undo()
+    sp = P.get_uniformly_sampled_pts(5, 12, (96, 160), device=DEV)
+    assert tuple(sp.shape) == (1, 5, 3) and float(sp[0, :, 1].max()) < 160 and float(sp[0, :, 2].max()) < 96
+
+
+@pytest.mark.parametrize("name", ["g4_xyz", "g2_nooffset", "g1_k8_xyz"])
+def test_forward_corr_options_golden(golden, name):
+    """The reference's non-default correlation layouts end to end on the device (mvt_corr_gather_dot_opts, generic token / input
+    transform paths) against the reference fixture: fp32 at the north-star tolerance, bf16 (composite updater with a token matrix,
+    or the fused input path when the token width allows) within the bf16 bar of the default layout."""
+    from mvtracker_amd.tracker import MVTracker
+    from test_oracle_golden import CORR_OPT_CASES, corr_opts_clip
+    g = golden("e2e_corr_opts")
+    m = MVTracker(hidden_size=256, **CORR_OPT_CASES[name]).eval()
+    assert m.updateformer_input_dim == int(g[name + "_token_dim"])
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV)
+    a = args_of(corr_opts_clip(g), DEV)
+    ref = g[name + "_traj"]
+    m.precision = "fp32"
+    r = m(*a, iters=3)
+    torch.cuda.synchronize()
+    m.check_finite()
+    rel = np.abs(r["traj_e"].cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert rel < 1e-4, rel
+    assert np.abs(r["vis_e"].cpu().numpy() - g[name + "_vis"]).max() < 1e-3
+    m.precision = "bf16"
+    r = m(*a, iters=3)
+    torch.cuda.synchronize()
+    m.check_finite()
+    relb = np.abs(r["traj_e"].cpu().numpy() - ref).max() / np.abs(ref).max()
+    print(f"{name}: fp32 {rel:.2e}, bf16 {relb:.2e}")
+    assert relb < 2.5e-3, relb

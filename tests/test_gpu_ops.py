@@ -554,6 +554,44 @@ def test_corr_sample_golden(hip, golden):
     assert np.abs(out.numpy() - g["out_exact"]).max() < 2e-5
 
 
+@pytest.mark.parametrize("bf", [False, True])
+@pytest.mark.parametrize("G_,off,xyz_", [(4, True, True), (2, False, False), (1, True, True), (16, True, False), (1, False, True)])
+def test_corr_gather_dot_options(hip, golden, bf, G_, off, xyz_):
+    """mvt_corr_gather_dot_opts: grouped dots / no offsets / neighbour coordinates (mvtracker.py:832-846) against the oracle on random
+    clouds, fp32 and bf16 rows; the (k = 8, 4 groups, offsets + coordinates) case additionally against the reference fixture."""
+    g = torch.Generator().manual_seed(100 + G_)
+    B, P, M, K, C = 2, 3000, 37, 16, 128
+    xyz = torch.rand(B, P, 3, generator=g) * 2 - 1
+    fvec = torch.randn(B, P, C, generator=g)
+    if bf:
+        fvec = fvec.bfloat16().float()
+    tg, cd = torch.randn(B, M, C, generator=g), torch.rand(B, M, 3, generator=g) * 2 - 1
+    ref, ridx = O.corr_sample(xyz, fvec, tg, cd, K, G_, off, xyz_, "exact", return_idx=True)
+    x4 = torch.zeros(B, P, 4)
+    x4[..., :3] = xyz
+    OW = G_ + 3 * off + 3 * xyz_
+    out = torch.zeros(M, B, 2 + K * OW, device=DEV)
+    hip.corr_gather_dot_opts([G(x4)], [G(fvec.bfloat16() if bf else fvec)], [P], [G(ridx.permute(1, 0, 2).int())], C, G(tg.permute(1, 0, 2)),
+                             G(cd.permute(1, 0, 2)), M, B, 0, 1, B, K, G_, off, xyz_, out, 2 + K * OW, 2)
+    torch.cuda.synchronize()
+    assert float(out[..., :2].abs().max()) == 0.0
+    got = out[..., 2:].reshape(M, B, K, OW).permute(1, 0, 2, 3).cpu()
+    assert (got - ref).abs().max() < 2e-5
+    if (G_, off, xyz_) == (4, True, True) and not bf:
+        gg = golden("corr_sample_small")
+        xyz, fvec, tg, cd = T(gg["xyz"]), T(gg["fvec"]), T(gg["targets"]), T(gg["coords"])
+        B, P, C = fvec.shape
+        M = tg.shape[1]
+        _, ridx = O.corr_sample(xyz, fvec, tg, cd, 8, 4, True, True, "exact", return_idx=True)
+        x4 = torch.zeros(B, P, 4)
+        x4[..., :3] = xyz
+        out = torch.zeros(M, B, 8 * 10, device=DEV)
+        hip.corr_gather_dot_opts([G(x4)], [G(fvec)], [P], [G(ridx.permute(1, 0, 2).int())], C, G(tg.permute(1, 0, 2)), G(cd.permute(1, 0, 2)), M, B,
+                                 0, 1, B, 8, 4, True, True, out, 80, 0)
+        torch.cuda.synchronize()
+        assert np.abs(out.reshape(M, B, 8, 10).permute(1, 0, 2, 3).cpu().numpy() - gg["out_exact_k8_g4_xyz"]).max() < 2e-5
+
+
 @pytest.mark.parametrize("P,K,nseg,M", [(20000, 16, 2, 37), (65536, 16, 4, 16), (5000, 1, 1, 20), (40000, 1, 4, 9), (16, 16, 1, 5),
                                         (1000, 8, 1, 64)])
 def test_knn_exact_vs_oracle(hip, P, K, nseg, M):

@@ -41,6 +41,26 @@ def test_constructor_rejects_unsupported():
         MVTracker(normalize_scene_in_fwd_pass=True)
     with pytest.raises(NotImplementedError):
         MVTracker(corr_filter_invalid_depth=True)
+    with pytest.raises(NotImplementedError):
+        MVTracker(corr_n_groups=3)  # (grouped dots: a power of two <= fmaps_dim / 8)
+
+
+@pytest.mark.parametrize("name", ["g4_xyz", "g2_nooffset", "g1_k8_xyz"])
+def test_forward_corr_options(monkeypatch, golden, name):
+    """Non-default correlation layouts through the host logic (token width, input transform shape, correlation row layout) on the
+    mocked kernels, against the reference fixture."""
+    from test_oracle_golden import CORR_OPT_CASES, corr_opts_clip
+    hip_mock.install(monkeypatch)
+    g = golden("e2e_corr_opts")
+    m = MVTracker(hidden_size=256, **CORR_OPT_CASES[name]).eval()
+    assert m.updateformer_input_dim == int(g[name + "_token_dim"])
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    clip = corr_opts_clip(g)
+    r = m(T(clip["rgbs"]), T(clip["depths"]), T(clip["query_points"]), T(clip["intrs"]), T(clip["extrs"]), iters=3)
+    ref = g[name + "_traj"]
+    assert np.abs(r["traj_e"].numpy() - ref).max() / np.abs(ref).max() < 1e-3
+    np.testing.assert_allclose(r["vis_e"].numpy(), g[name + "_vis"], atol=2e-2)  # (mocked kernels: torch arithmetic, layout check)
 
 
 def test_cpu_tensors_are_refused():

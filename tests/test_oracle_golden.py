@@ -337,3 +337,47 @@ def test_evaluate_3dpt_oracle_vs_reference(golden, name):
     got = MO.evaluate_3dpt(g[f"{name}_gt"], g[f"{name}_vis"], g[f"{name}_pred"], g[f"{name}_pvis"], str(g[f"{name}_setting"][0]),
                            float(g[f"{name}_upscale"][0]), qp)
     check_evaluate_3dpt_against_golden(g, name, got)
+
+
+def test_predictor_uniform_support_points(golden, W):
+    """num_uniformly_sampled_pts > 0 (evaluation_predictor_3dpt.py:147-190, 417-429) against the reference: the sampler makes the
+    same two draws in the same order (same CPU generator state -> the recorded points, bit for bit), and the oracle fed those
+    points reproduces the model's query rows and the tracks."""
+    from mvtracker_amd.predictor import get_uniformly_sampled_pts
+    g = golden("predictor_uniform_pts")
+    torch.manual_seed(int(g["torch_seed"]))
+    sp = get_uniformly_sampled_pts(6, 12, (96, 160), device="cpu")[0]
+    assert np.array_equal(sp.numpy(), g["sampled_pts"])
+    clip = synth.make_clip(int(g["clip_seed"]), V=2, T=12, H=96, W=160, N=4)
+    a = [T(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
+    r = O.predictor_forward(W, CFG, *a, interp_shape=None, grid_size=2, n_iters=2, uniform_pts=T(g["sampled_pts"]))
+    q = torch.cat([a[2], r["support_points"]], 1)
+    close(q, g["model_query_points"], rtol=1e-5, atol=1e-5)
+    ref = g["traj_e"]
+    assert np.abs(r["traj_e"].numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    close(r["vis_e_as_prob"], g["vis_e_as_prob"], rtol=0, atol=1e-3)
+
+
+CORR_OPT_CASES = {"g4_xyz": dict(corr_n_groups=4, corr_add_neighbor_offset=True, corr_add_neighbor_xyz=True),
+                  "g2_nooffset": dict(corr_n_groups=2, corr_add_neighbor_offset=False, corr_add_neighbor_xyz=False),
+                  "g1_k8_xyz": dict(corr_n_groups=1, corr_neighbors=8, corr_add_neighbor_offset=True, corr_add_neighbor_xyz=True)}
+
+
+def corr_opts_clip(g):
+    return synth.make_clip(int(g["clip_seed"]), V=2, T=18, H=128, W=128, N=10, late_queries=True, query_frames=(3, 7))
+
+
+@pytest.mark.parametrize("name", list(CORR_OPT_CASES))
+def test_corr_options_end_to_end_oracle(golden, name):
+    """The reference's non-default correlation layouts (grouped dots, no offsets, neighbour coordinates; mvtracker.py:130-149,
+    832-846) end to end: the oracle against the reference fixture (tests/golden/make_golden_corr_opts.py), two windows, late queries."""
+    g = golden("e2e_corr_opts")
+    cfg = O.TrackerConfig(**CORR_OPT_CASES[name])
+    assert cfg.token_dim == int(g[name + "_token_dim"])
+    clip = corr_opts_clip(g)
+    a = [T(clip[k]) for k in ("rgbs", "depths", "query_points", "intrs", "extrs")]
+    with torch.no_grad():
+        r = O.tracker_forward(O.make_weights(cfg, 0), cfg, *a, iters=3, knn_mode="exact")
+    ref = g[name + "_traj"]
+    assert np.abs(r["traj_e"].numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    close(r["vis_e"], g[name + "_vis"], rtol=0, atol=1e-3)
