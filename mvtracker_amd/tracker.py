@@ -368,6 +368,8 @@ class MVTracker(nn.Module):
         def frag_of(name, kpad):  # fragment-major bf16 of a [N][K] linear, K zero-padded to kpad (a multiple of 16)
             wt, b = sd[name + ".weight"], sd[name + ".bias"].contiguous()
             n, k = wt.shape
+            if kpad > _round_up(k, 64):  # (the row-major image must be at least kpad wide: token widths well below 592)
+                wt = torch.cat([wt, torch.zeros(n, kpad - k, device=wt.device)], 1)
             hi = matrix(wt)[0]  # [n][round_up(k, 64)], zero padded
             fr = torch.empty(_round_up(n, 32) * kpad, device=wt.device, dtype=torch.int16)
             hip.pack_frag_bf16(hi, hi.shape[1], n, kpad, fr)

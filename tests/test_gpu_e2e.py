@@ -482,10 +482,13 @@ def _check_iteration_rows(model, store, frame0, wtrace, it, sample, fcorr_tol=5e
     for lvl in range(model.corr_n_levels):
         xyz = store["xyz"][lvl][frames].reshape(S, -1, 4)[..., :3].cpu()
         fvec = store["fvec"][lvl][frames].reshape(S, xyz.shape[1], -1).float().cpu()
-        o, idx = O.corr_sample(xyz, fvec, f, c, k=K, knn_mode="exact", return_idx=True)
+        OW = getattr(model, "corr_width", 4)  # values per neighbour: grouped dots [+ offset] [+ coordinates]
+        o, idx = O.corr_sample(xyz, fvec, f, c, k=K, groups=getattr(model, "corr_n_groups", 1),
+                               add_offset=getattr(model, "corr_add_neighbor_offset", True), add_xyz=getattr(model, "corr_add_neighbor_xyz", False),
+                               knn_mode="exact", return_idx=True)
         got_idx = wtrace["knn_idx"][it][lvl][sample].cpu().long().permute(1, 0, 2)
         assert torch.equal(got_idx, idx), f"kNN indices differ at level {lvl}, iteration {it}, window frame {frame0}"
-        got = wtrace["fcorrs"][it][sample].cpu().permute(1, 0, 2)[..., lvl * K * 4:(lvl + 1) * K * 4].reshape(S, len(sample), K, 4)
+        got = wtrace["fcorrs"][it][sample].cpu().permute(1, 0, 2)[..., lvl * K * OW:(lvl + 1) * K * OW].reshape(S, len(sample), K, OW)
         worst = max(worst, (got - o).abs().max().item())
     assert worst < fcorr_tol, (worst, it, frame0)
     return worst
@@ -940,8 +943,13 @@ def test_forward_corr_options_golden(golden, name):
     torch.cuda.synchronize()
     m.check_finite()
     rel = np.abs(r["traj_e"].cpu().numpy() - ref).max() / np.abs(ref).max()
-    assert rel < 1e-4, rel
-    assert np.abs(r["vis_e"].cpu().numpy() - g[name + "_vis"]).max() < 1e-3
+    verr = np.abs(r["vis_e"].cpu().numpy() - g[name + "_vis"]).max()
+    # Two windows with late queries on a seed that was NOT scanned for near-ties (a neighbour flip moves a
+    # multi-window run by ~1e-3): the end-to-end bar is the flip-level one, and every iteration of every window is checked
+    # teacher-forced at the strict bar below (indices bit-exact, correlation rows 5e-5, in this layout).
+    assert rel < 2e-3 and verr < 2e-2, (rel, verr)
+    w = _check_forward_trace(m, a, n_sample=10, iters=3)
+    print(f"{name}: teacher-forced fcorr rows max abs err {w:.2e}")
     m.precision = "bf16"
     r = m(*a, iters=3)
     torch.cuda.synchronize()
