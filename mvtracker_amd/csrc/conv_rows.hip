@@ -72,6 +72,95 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
                                               int n0, int tiles_x, int tx, int lane, unsigned short* stage, float* wst, int lrow0) {
   constexpr int BNS = TN * 32;
   const int r = lane & 31, h = lane >> 5;
+#ifndef MVT_EPI_NO_TR
+  if constexpr (STAGED && TN * 32 * 36 <= stage_elems<TN>()) {  // (96-channel tiles: the transposed tile does not fit their staging area)
+    // Round 3: bf16 output through a TRANSPOSED staging tile.  The accumulator layout has the channel on the lane and four runs of
+    // four consecutive pixels in the registers: as [pixel][channel] staging every value was its own 2-byte LDS store (16 per 32 x 32
+    // block and lane; in-kernel stamps: the epilogue of a 64-channel tile cost as much as its MFMAs).  Staged as [channel][pixel]
+    // (72-B rows: conflict-free) a lane stores each run of four pixels as ONE 8-byte word -- 4 stores per block -- and the tile is read
+    // back with gfx950's transposing ds_read_b64_tr_b16 (per 16-lane group: 4 channel rows x 16 pixels, delivered to lane i as the
+    // four channels of pixel i): two such reads give a lane eight consecutive channels of one pixel = one 16-byte global store.
+    // Same values, same rounding, same statistics as the [pixel][channel] form: bit-identical outputs.
+    // The wave-level fences around the staging tile are scoped to LDS ("local"): unscoped they also wait for the row's GLOBAL
+    // stores to complete (s_waitcnt vmcnt(0), a full write round trip per tile row) before the next row may touch the tile.
+    constexpr int BN = TN * 32, LDTT = 36;   // staging row = 32 pixels + 4 pad (bf16)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const bool interior = x0 + TC <= Wo;
+    const int gq = lane >> 4, li = lane & 15;  // 16-lane group, lane in group
+    // the biases of all channel blocks are requested up front: one memory round trip per tile instead of one per 32 x 32 block
+    // (a persistent workgroup has no neighbour to hide them behind)
+    float bvs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bvs[j] = (p.bias && n0 + j * 32 + r < p.Cout) ? p.bias[n0 + j * 32 + r] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int y = yw + i;  // wave-uniform
+      if (y >= Ho) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32 + r;
+        const bool nok = n < p.Cout;
+        const float bv = bvs[j];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = acc[i][j][4 * g + e] + bv;
+            v4[e] = v;
+            if (nok && (interior || x0 + 8 * g + 4 * h + e < Wo)) {
+              s1 += v;
+              s2 = fmaf(v, v, s2);
+            }
+          }
+          *reinterpret_cast<u32x2*>(&stage[(j * 32 + r) * LDTT + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, __builtin_convertvector(v4, bf16x4));
+        }
+        if (p.out_part) {  // one writer per (tile row, channel): deterministic
+          // (lane pair (l, l ^ 32) summed with v_permlane32_swap: the two results hold the pair's lower and upper value in every
+          //  lane, their sum is the same bits as x + shfl_xor(x, 32) without the LDS round trip of a ds_bpermute)
+          const auto q1 = __builtin_amdgcn_permlane32_swap(__float_as_int(s1), __float_as_int(s1), false, false);
+          const auto q2 = __builtin_amdgcn_permlane32_swap(__float_as_int(s2), __float_as_int(s2), false, false);
+          s1 = __int_as_float(q1[0]) + __int_as_float(q1[1]);
+          s2 = __int_as_float(q2[0]) + __int_as_float(q2[1]);
+          if (h == 0 && nok) {
+            float* pp = wst + ((lrow0 + i) * BNS + j * 32 + r) * 2;
+            pp[0] = s1;
+            pp[1] = s2;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one 32 x 32 block at a time (VGPR budget)
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+      unsigned short* rowp = reinterpret_cast<unsigned short*>(p.out) + ((img * Ho + y) * (long long)Wo + x0) * p.ldo + n0;
+      // pair k: group gq reads channel octet m = 2 k + (gq >> 1) of pixels 16 (gq & 1) .. + 15; lane 4 q + pp of a group supplies the
+      // address of channel row q, pixel columns 4 pp .. 4 pp + 3 (EXEC is all ones here: no lane may be masked for the gather)
+      const int ph = gq & 1;
+      const unsigned short* tb = stage + (li >> 2) * LDTT + ph * 16 + (li & 3) * 4;
+      // (all transposed reads of the row first, then its stores: one LDS latency per row instead of one per pair)
+      s16x4 lo[BN / 16], hi[BN / 16];
+#pragma unroll
+      for (int k = 0; k < BN / 16; ++k) {
+        const int m = 2 * k + (gq >> 1);
+        lo[k] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb + (8 * m) * LDTT));
+        hi[k] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb + (8 * m + 4) * LDTT));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int px = ph * 16 + li;
+      unsigned short* lanep = rowp + (long long)px * p.ldo;
+#pragma unroll
+      for (int k = 0; k < BN / 16; ++k) {
+        const int m = 2 * k + (gq >> 1);
+        if (x0 + px < Wo && n0 + 8 * m < p.Cout) {
+          const u32x2 a = __builtin_bit_cast(u32x2, lo[k]), b2 = __builtin_bit_cast(u32x2, hi[k]);
+          *reinterpret_cast<u32x4*>(lanep + 8 * m) = (u32x4){a[0], a[1], b2[0], b2[1]};
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+    }
+    return;
+  }
+#endif
   if (STAGED) {  // (compile-time: with both paths in one kernel the accumulators are copied out ahead of the branch -> +50 VGPRs)
     // bf16 output through LDS: the accumulator layout (channel on the lane, 16 pixels in the registers) would store 2-4 bytes
     // per lane; staged as [pixel][channel], every lane stores 16 contiguous bytes and a pixel's channels leave as whole
@@ -110,7 +199,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
         }
         __builtin_amdgcn_sched_barrier(0);  // one 32 x 32 block at a time: a single VGPR decides the occupancy of these kernels
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the tile is written as 16-bit elements and read as 128-bit vectors
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");  // the tile is written as 16-bit elements and read as 128-bit vectors
       unsigned short* rowp = reinterpret_cast<unsigned short*>(p.out) + ((img * Ho + y) * (long long)Wo + x0) * p.ldo + n0;
 #pragma unroll
       for (int k = 0; k < (32 * PPX + 63) / 64; ++k) {
@@ -119,7 +208,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
         if (pc < 32 * PPX && x0 + px < Wo && n0 + c8 * 8 < p.Cout)
           *reinterpret_cast<u32x4*>(rowp + (long long)px * p.ldo + c8 * 8) = *reinterpret_cast<const u32x4*>(&stage[px * LDT + c8 * 8]);
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
     }
     return;
   }

@@ -123,6 +123,7 @@ def test_conv2d(hip, cfg, prec):
 
 
 @pytest.mark.parametrize("cfg", [(2, 24, 40, 64, 96, 3, 1, 1), (3, 17, 21, 32, 64, 3, 1, 1), (2, 32, 64, 64, 96, 3, 2, 1),
+                                 (2, 24, 40, 64, 64, 3, 1, 1), (3, 17, 21, 64, 64, 3, 1, 1), (5, 64, 96, 64, 64, 3, 1, 1),
                                  (2, 32, 32, 96, 128, 1, 2, 0), (1, 64, 64, 3, 64, 7, 2, 3)])
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
 def test_conv2d_fused_instnorm(hip, cfg, prec):
@@ -175,6 +176,7 @@ def test_conv2d_fused_instnorm(hip, cfg, prec):
 
 
 @pytest.mark.parametrize("cfg", [(2, 24, 40, 64, 96, 3, 1, 1), (2, 32, 64, 64, 96, 3, 2, 1), (2, 32, 32, 96, 128, 1, 2, 0),
+                                 (2, 24, 40, 64, 64, 3, 1, 1), (3, 17, 21, 64, 64, 3, 1, 1), (9, 64, 96, 64, 64, 3, 1, 1),
                                  (1, 64, 64, 3, 64, 7, 2, 3), (1, 16, 24, 416, 256, 3, 1, 1)])
 def test_conv2d_bf16_activation_tensors(hip, cfg):
     """bf16 activation tensors (bf16 mode): same arithmetic as fp32 tensors holding the bf16 values, output rounded
