@@ -170,6 +170,21 @@ int mvt_block_fused_bf16(float* x, int ldx, const void* att /* fp32, or bf16 whe
  *                  frame, the virtual tokens: M = 64 * S); the kernel combines the n_splits partial states itself -- same
  *                  arithmetic and order as the merge launch it replaces -- instead of reading a merged attention tensor. */
 #define MVT_ATTN_PARTIALS 3
+/*   MVT_ATTN_FRAME_CTX: MVT_ATTN_FRAME (M >= 4096, n_keys == 64) whose context tokens are the rows of a split-path block called
+ *                  with defer_pass2: that block's second launch is skipped and every workgroup here finishes the context rows of
+ *                  its frame itself (x = x_mid + b2 + partial sums in pass 2's order, LayerNorm, k|v projection -- bit-identical
+ *                  to the pass-2 launch), keeps k|v in LDS, and the context's x / one further projection are written once per
+ *                  frame.  k, v are unused.  One launch and one write-then-read of k|v less per updater layer. */
+#define MVT_ATTN_FRAME_CTX 4
+typedef struct mvt_block_ctx {
+  const float* ws;     /* the `workspace` of the deferred block: (chunks + 1) * 64 * S * C floats */
+  int chunks;          /* its H / 256 */
+  const float* b2;     /* its fc2 bias */
+  float* x;            /* its x rows [64 * S][ldx] (row = token * S + frame): final values are written here */
+  int ldx;
+  mvt_block_next kv;   /* LayerNorm + k|v projection of the context rows: N = 576 (k | v, 6 heads x 48); y is not written */
+  mvt_block_next next; /* optional (w == NULL: none): one more projection of the context rows, written to y [64 * S][ldy] */
+} mvt_block_ctx;
 typedef struct mvt_block_attn {
   int kind, S, n_keys, heads, dim_head, ldq, ldkv;
   const unsigned short* q;
@@ -177,6 +192,9 @@ typedef struct mvt_block_attn {
   const unsigned short* v;
   const float* partials; /* MVT_ATTN_PARTIALS: the workspace of mvt_attention_bf16 */
   int n_splits;
+  int defer_pass2;       /* split-path forms (workspace given, M < 4096): launch pass 1 only; x and the follow-up projections are
+                            finished by the consumer (MVT_ATTN_FRAME_CTX) */
+  const mvt_block_ctx* ctx; /* MVT_ATTN_FRAME_CTX */
 } mvt_block_attn;
 int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn* attn, const unsigned short* wo, const float* bo,
                               const unsigned short* w1, const float* b1, const unsigned short* w2, const float* b2, int H,
@@ -467,7 +485,9 @@ typedef struct mvt_updater_weights {
   int depth, hidden, heads, dim_head, n_virtual, S, token_dim, out_dim;
   int fuse_attention; /* bit 0: time attention, bit 1: point<-virtual, bit 2: virtual self attention run inside the block kernels
                          (mvt_attn_block_fused_bf16) instead of as separate launches; bit 3: unused (ignored); bit 4: the virtual<-point block
-                         combines the key-split partials (MVT_ATTN_PARTIALS, no merge launch); results are bit-identical either way */
+                         combines the key-split partials (MVT_ATTN_PARTIALS, no merge launch); bit 5 (with bits 1 and 2, >= 4096 point rows): the
+                         virtual-self block's second launch runs inside the point<-virtual block (MVT_ATTN_FRAME_CTX); results are
+                         bit-identical either way */
   const float* virtual_tokens; /* [n_virtual][hidden] */
   mvt_lin_rows input_transform, flow0, flow2, flow4;
   mvt_updater_block time_blk[MVT_UPDATER_MAX_DEPTH], v2p[MVT_UPDATER_MAX_DEPTH], vself[MVT_UPDATER_MAX_DEPTH], p2v[MVT_UPDATER_MAX_DEPTH];

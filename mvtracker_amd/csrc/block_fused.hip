@@ -122,6 +122,14 @@ struct BlockArgs {
   const float* t_pos;       // [n][D]
   const float* t_time;      // [S][D]
   int t_E, t_Fc, t_Cf, t_D;
+  // ATT 6: the 64 context tokens of the per-frame attention are the rows of a split-path block whose pass 2 was DEFERRED to this
+  // kernel (mvt_block_ctx): their x is finished here from the partial sums, LayerNorm + k|v projection feed the attention from LDS
+  const float* c_ws;        // split-path workspace of the context block: [c_nch + 1][S * 2 tiles][8 waves][4][64 lanes][4]
+  const float* c_b2;        // its fc2 bias
+  float* c_x;               // the context rows of the residual stream (row = token * S + frame), written by tile 0 of every frame
+  int c_ldx, c_nch;
+  mvt_block_next c_kv;      // LayerNorm + k|v projection of the context (N = 576; y unused: k|v never leave the CU)
+  mvt_block_next c_next;    // optional (w == null: none) further projection of the context rows, written to y
 };
 
 // gelu_tanh on a pair: x * sigmoid(2k), k = sqrt(2/pi) (x + 0.044715 x^3), as x / (1 + exp2(x (c0 + c1 x^2))) with
@@ -294,6 +302,7 @@ __device__ __forceinline__ void fill_wq(bf16x8 (&wq)[PFQ], const unsigned short*
 //   qrow(i) / krow(j): element row of query i / key j in q / k|v;  vt: this wave's V^T image [48][LDVA];  zrow: >= 40 zero
 //   elements (the d padding rows 48..63 of the second 32-row block);  arow0: tile row of query 0.
 constexpr int LDVA = 40, DHA = 48, VTA = DHA * LDVA;
+constexpr int LDKV = 584;  // bf16 row stride of the in-LDS context k|v tile of ATT 6 (2 * 288 columns + 8)
 // operands of one wave_attention unit, as loaded from global memory (NMBQ query blocks, NKB key blocks)
 template <int NMBQ, int NKB> struct AttnFrags {
   u32x4 q[NMBQ][3];   // lane (r, h) of block mb: Q[mb*32 + r][ks*16 + 8h .. +7]
@@ -592,17 +601,22 @@ template <int NMB, int MODE, int ATT>
 __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   using K_ = Cfg<NMB>;
   constexpr int BM = K_::BM, HC = K_::HC, LDH = K_::LDH, LDA = K_::LDA;
+  constexpr bool CTX = ATT == 6;  // ATT 2 with the context k|v derived in the kernel (deferred pass 2 of the context block)
+  static_assert(!CTX || (NMB == 2 && MODE == 0), "the context form runs on the 64-row tiles of the point rows");
+  // (ATT 6: the H buffers also hold the context's k|v tile [64][LDKV] during the prologue -- 74.8 KB instead of 67.6)
+  constexpr int HSZ = CTX && (64 * LDKV + 1) / 2 > BM * LDH ? (64 * LDKV + 1) / 2 : BM * LDH;
   __shared__ __attribute__((aligned(16))) unsigned short Xs[BM * LDX];
-  __shared__ __attribute__((aligned(16))) unsigned short Hs[2][BM * LDH];
+  __shared__ __attribute__((aligned(16))) unsigned short Hs[2][HSZ];
   __shared__ float st[8 * BM * 2];
   __shared__ __attribute__((aligned(16))) float b1s[4 * C];
+  __shared__ __attribute__((aligned(16))) float cbs[CTX ? 2 * 288 : 4];  // bias of the context's k|v projection
 
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
   static_assert(ATT == 0 || ATT == 5 || MODE != 2, "pass 2 of the split path has no attention");
   static_assert(ATT != 5 || MODE == 2, "ATT 5 = pass 2 on the frame-major tiles of an ATT 2 / ATT 3 pass 1");
   static_assert((MODE != 1 && MODE != 2) || NMB == 1, "the split path runs on 32-row tiles");
-  constexpr bool FM = ATT == 2 || ATT == 3 || ATT == 5;        // frame-major tile: tokens blockIdx.x*BM.. of frame blockIdx.z
+  constexpr bool FM = ATT == 2 || ATT == 3 || ATT == 5 || ATT == 6;  // frame-major tile: tokens blockIdx.x*BM.. of frame blockIdx.z
   const int bmv = ATT == 1 ? p.bmv : BM;                      // rows of the tile that hold tokens
   const long long m0 = FM ? 0 : (long long)blockIdx.x * bmv;
   const long long ntok = FM ? p.M / p.S : 0;                   // tokens per frame
@@ -647,6 +661,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   auto prefetch_wo = [&]() { fill_wq(wq, wo_row); };
   if (HAS_MLP && !outp) {
     fill_wq(wq, fc1_first);
+  } else if (CTX) {
+    // (the queue starts with the context's k|v projection, requested below once the partial sums' registers are free)
   } else if (outp) {
     prefetch_wo();
   } else if (EARLY && MODE == 2) {
@@ -687,6 +703,126 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     wx[1] = ldg_frag(wo_row + 17 * FS);
     load_x();
   };
+
+  // ---- 0. (ATT 6) the DEFERRED PASS 2 of the context block.  The 64 context tokens of this frame (the virtual tracks) went through
+  // pass 1 of the split path in the previous launch; instead of a pass-2 launch finishing them (x = x_mid + b2 + partial sums, then
+  // LayerNorm + k|v projection into a tensor that this kernel reads back) every workgroup of the frame finishes them itself: same
+  // loads, the same fixed summation order, LayerNorm and GEMM arithmetic as pass 2 (bit-identical), the k|v tile stays in LDS.
+  // One launch and one dependent read of freshly written data less per layer; tile 0 of the frame stores the context's x, the first
+  // workgroups of the frame evaluate the optional further projection of the context rows (the next layer's time q|k|v), 8 column
+  // blocks each.
+  if constexpr (CTX) {
+    unsigned short* KV = &Hs[0][0];
+    for (int i = t; i < 2 * 288; i += NT) cbs[i] = p.c_kv.b[i];
+    const long long ctile = 2LL * gridDim.z;
+    auto cws_off = [&](int chunk, int mb, int g) -> long long {
+      return ((((long long)chunk * ctile + (long long)blockIdx.z * 2 + mb) * 8 + wave) * 4 + g) * 256 + lane * 4;
+    };
+    constexpr int MAXCH = 4;
+    const int nch = p.c_nch;
+    f32x16 cv[2];
+    {
+      f32x4 part[2][4][MAXCH + 1], b2v[4];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int sidx = 0; sidx <= MAXCH; ++sidx)
+            part[mb][g][sidx] = sidx <= nch ? *reinterpret_cast<const f32x4*>(p.c_ws + cws_off(sidx, mb, g)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b2v[g] = *reinterpret_cast<const f32x4*>(p.c_b2 + wave * 32 + 8 * g + 4 * h);
+      __builtin_amdgcn_sched_barrier(0);  // (all loads ahead of the first add)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 xv = part[mb][g][0];
+#pragma unroll
+          for (int sidx = 1; sidx <= MAXCH; ++sidx)
+            if (sidx <= nch) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) xv[e] += part[mb][g][sidx][e];
+            }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cv[mb][4 * g + e] = 0.f + (xv[e] + b2v[g][e]);  // (pass 2 accumulates into a zero: same bits)
+        }
+    }
+    auto krow_w = [&](int nb) { return p.c_kv.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
+    auto nrow_w = [&](int nb) { return p.c_next.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
+    fill_wq(wq, krow_w(wave));  // (18 column blocks: every wave has a first one)
+    if (blockIdx.x == 0) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const long long m = (long long)(mb * 32 + r) * p.S + (long long)blockIdx.z;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = cv[mb][4 * g + e];
+          *reinterpret_cast<f32x4*>(p.c_x + m * (long long)p.c_ldx + wave * 32 + 8 * g + 4 * h) = o;
+        }
+      }
+    }
+    float cms[2][2];
+    ln_to_lds<2>(cv, Xs, st, wave, lane, p.c_kv.eps, p.c_kv.lnw, p.c_kv.lnb, cms, false);
+    const int nnb = p.c_next.w ? (p.c_next.N + 31) / 32 : 0;
+    const bool do_next = (int)blockIdx.x * 8 < nnb;  // (workgroup-uniform)
+    const int nbn = (int)blockIdx.x * 8 + wave;
+    const bool my_next = nbn < nnb;
+    constexpr int KVB = 2 * 288 / 32;
+#pragma unroll 1
+    for (int nb = wave; nb < KVB; nb += 8) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
+      gemm_wq<C / 16, 2>(acc, wq, krow_w(nb), nb + 8 < KVB ? krow_w(nb + 8) : (my_next ? nrow_w(nbn) : wo_row), &Xs[r * LDX + 8 * h], LDX, 0);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[mb][4 * g + e] + cbs[nb * 32 + 8 * g + 4 * h + e];
+          *reinterpret_cast<u32x2*>(&KV[(mb * 32 + r) * LDKV + nb * 32 + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, __builtin_convertvector(o, bf16x4));
+        }
+    }
+    if (do_next) {
+      __syncthreads();  // every wave is done reading Xs; st (the statistics scratch) is idle: it carries the projection's bias
+      for (int i = t; i < p.c_next.N; i += NT) st[i] = p.c_next.b[i];
+      ln_to_lds<2>(cv, Xs, st, wave, lane, p.c_next.eps, p.c_next.lnw, p.c_next.lnb, cms, true);
+      if (my_next) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
+        gemm_wq<C / 16, 2>(acc, wq, nrow_w(nbn), wo_row, &Xs[r * LDX + 8 * h], LDX, 0);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const long long m = (long long)(mb * 32 + r) * p.S + (long long)blockIdx.z;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = nbn * 32 + 8 * g + 4 * h;
+            if (n + 3 < p.c_next.N) {
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = acc[mb][4 * g + e] + st[n + e];
+              store_act4(p.c_next.y, m * (long long)p.c_next.ldy + n, o, p.c_next.y_bf16);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.c_next.N) store_act(p.c_next.y, m * (long long)p.c_next.ldy + n + e, acc[mb][4 * g + e] + st[n + e], p.c_next.y_bf16);
+            }
+          }
+        }
+      }
+      __syncthreads();  // st is about to become the attention's zero row
+    }
+    // (the barrier that publishes the k|v tile and frees Xs is the one at the head of the attention phase below)
+  }
 
   // ---- 1. attention output projection (accumulated into v, x is added afterwards)
   if (MODE == 3 && ATT == 4) {
@@ -897,14 +1033,24 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         attn_load<NMB, 2>(fr, p.aq, p.ldaq, row, nrow, p.ak, p.av, p.ldakv, row, nrow, wave, lane);
         attn_compute<NMB, 2>(fr, nrow, nrow, wave, vt, zrow, As, LDA, 0, lane, p.S, vstride);
       }
-    } else if (wave < 6 && grow(0) >= 0) {
+    } else {
+      const bool on = wave < 6 && grow(0) >= 0;
       const long long left = ntok - (long long)blockIdx.x * BM;
       const int nq = left < BM ? (int)left : BM;
       auto qrow = [&](int i) { return ((long long)blockIdx.x * BM + i) * p.S + (long long)blockIdx.z; };
-      auto krow = [&](int j) { return (long long)j * p.S + (long long)blockIdx.z; };
       AttnFrags<NMB, 2> fr;
-      attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, lane);
-      attn_compute<NMB, 2>(fr, nq, p.nkeys, wave, vt, zrow, As, LDA, 0, lane, 0, vstride);
+      if (CTX) {
+        // k|v of the frame's context tokens from the LDS tile of step 0 (tile row = context token); the tile lives where the
+        // attention output and the V^T images go: every wave holds its operands in registers before the first of them is written
+        const unsigned short* KV = &Hs[0][0];
+        auto krow = [&](int j) { return (long long)j; };
+        if (on) attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, KV, KV + 288, LDKV, krow, p.nkeys, wave, lane);
+        __syncthreads();
+      } else {
+        auto krow = [&](int j) { return (long long)j * p.S + (long long)blockIdx.z; };
+        if (on) attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, lane);
+      }
+      if (on) attn_compute<NMB, 2>(fr, nq, p.nkeys, wave, vt, zrow, As, LDA, 0, lane, 0, vstride);
     }
     pre_gemm();
     STAMP(2);
@@ -1271,7 +1417,7 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
   MVT_REQUIRE(x && attn && wo && bo && w1 && b1 && w2 && b2 && M > 0 && Cc == C && H > 0 && H % 256 == 0 && H <= 4 * C);
   MVT_REQUIRE(ldx % 4 == 0 && ldx >= C && n_next >= 0 && n_next <= MVT_BLOCK_MAX_NEXT && (n_next == 0 || next));
   MVT_REQUIRE(attn->heads == 6 && attn->dim_head == DHA && attn->S >= 1 && M % attn->S == 0);
-  MVT_REQUIRE(attn->kind == MVT_ATTN_PARTIALS ||
+  MVT_REQUIRE(attn->kind == MVT_ATTN_PARTIALS || (attn->kind == MVT_ATTN_FRAME_CTX && attn->q && attn->ldq % 8 == 0 && attn->ldq >= 288) ||
               (attn->q && attn->k && attn->v && attn->ldq % 8 == 0 && attn->ldkv % 8 == 0 && attn->ldq >= 288 && attn->ldkv >= 288));
   MVT_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)wo % 16 == 0) && ((uintptr_t)w1 % 16 == 0) && ((uintptr_t)w2 % 16 == 0));
   MVT_REQUIRE(((uintptr_t)attn->q % 16 == 0) && ((uintptr_t)attn->k % 16 == 0) && ((uintptr_t)attn->v % 16 == 0));
@@ -1305,7 +1451,8 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
     for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
     const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
     (void)tiles;  // pass 2 on the SAME frame-major tiles (the workspace is tile-native)
-    hipLaunchKernelGGL((block_fused_bf16<1, 2, 5>), dim3(2, slices, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
+    if (!attn->defer_pass2)
+      hipLaunchKernelGGL((block_fused_bf16<1, 2, 5>), dim3(2, slices, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
   } else if (attn->kind == MVT_ATTN_FRAME) {
     MVT_REQUIRE(attn->n_keys >= 1 && attn->n_keys <= 64);
     const long long ntok = M / S;
@@ -1321,8 +1468,27 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
       int maxblk = 1;
       for (int q = 0; q < n_next; ++q) maxblk = (next[q].N + 31) / 32 > maxblk ? (next[q].N + 31) / 32 : maxblk;
       const unsigned slices = n_next ? (unsigned)mvt_cdiv(maxblk, 8) : 1u;
-      hipLaunchKernelGGL((block_fused_bf16<1, 2, 5>), dim3((unsigned)(ntok / 32), slices, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
+      if (!attn->defer_pass2)
+        hipLaunchKernelGGL((block_fused_bf16<1, 2, 5>), dim3((unsigned)(ntok / 32), slices, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
     }
+  } else if (attn->kind == MVT_ATTN_FRAME_CTX) {
+    // per-frame attention whose 64 context tokens are the rows of a split-path block with a deferred pass 2 (ATT 6)
+    const mvt_block_ctx* cx = attn->ctx;
+    const long long ntok = M / S;
+    MVT_REQUIRE(cx && attn->n_keys == 64 && ntok * S >= 4096 && !workspace && !attn->defer_pass2);
+    MVT_REQUIRE(cx->ws && cx->b2 && cx->x && cx->chunks >= 1 && cx->chunks <= 4 && cx->ldx % 4 == 0 && cx->ldx >= C);
+    MVT_REQUIRE(((uintptr_t)cx->ws % 16 == 0) && ((uintptr_t)cx->b2 % 16 == 0) && ((uintptr_t)cx->x % 16 == 0));
+    MVT_REQUIRE(cx->kv.w && cx->kv.b && cx->kv.N == 2 * 288 && (cx->kv.lnw == nullptr) == (cx->kv.lnb == nullptr));
+    MVT_REQUIRE(((uintptr_t)cx->kv.w % 16 == 0) && ((uintptr_t)cx->kv.lnw % 16 == 0) && ((uintptr_t)cx->kv.lnb % 16 == 0));
+    const unsigned tiles = (unsigned)mvt_cdiv(ntok, 64);
+    if (cx->next.w) {
+      const mvt_block_next& nx = cx->next;
+      MVT_REQUIRE(nx.b && nx.y && nx.N > 0 && nx.N <= 4 * C && nx.ldy % 4 == 0 && nx.ldy >= nx.N && (nx.y_bf16 == 0 || nx.y_bf16 == 1));
+      MVT_REQUIRE((nx.lnw == nullptr) == (nx.lnb == nullptr) && ((uintptr_t)nx.lnw % 16 == 0) && ((uintptr_t)nx.lnb % 16 == 0));
+      MVT_REQUIRE(((uintptr_t)nx.w % 16 == 0) && ((uintptr_t)nx.y % 16 == 0) && (nx.N + 31) / 32 <= 8 * (int)tiles);
+    }
+    a.c_ws = cx->ws; a.c_b2 = cx->b2; a.c_x = cx->x; a.c_ldx = cx->ldx; a.c_nch = cx->chunks; a.c_kv = cx->kv; a.c_next = cx->next;
+    hipLaunchKernelGGL((block_fused_bf16<2, 0, 6>), dim3(tiles, 1, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
   } else {
     return MVT_ERR_ARG;
   }

@@ -115,6 +115,8 @@ static int updater_run(const mvt_updater_weights* w, const float* x, int ldx, co
     return mvt_attn_block_fused_bf16(xr, H_, &at, b.out.w, b.out.b, b.fc1.w, b.fc1.b, b.fc2.w, b.fc2.b, MLP, nx, nn, rows, H_, ws, stream);
   };
   const bool fuse_time = (w->fuse_attention & 1) && S <= 32, fuse_p2v = (w->fuse_attention & 2) != 0, fuse_vs = (w->fuse_attention & 4) != 0;
+  // bit 5: the virtual-self block's pass 2 runs inside the point<-virtual block (needs both attentions in their block kernels)
+  const bool fold_vs = (w->fuse_attention & 32) && fuse_p2v && fuse_vs && (long long)n * S >= 4096 && MLP / 256 <= 4;
 
   // tokens: input transform of the point rows, learned virtual tokens repeated over the S frames (blocks.py:456-459), and the
   // first time-attention q|k|v projection -- one launch when the fragment-major input weights are available
@@ -175,7 +177,15 @@ static int updater_run(const mvt_updater_weights* w, const float* x, int ldx, co
       mvt_block_next nx[2] = {next_of(p2v.kv, qv + INNER, ld3, 0, 0, p2v.ctx_ln_w, p2v.ctx_ln_b, 1e-5f), {}};
       int nn = 1;
       if (!last) nx[nn++] = next_of(w->time_blk[i + 1].qkv, qkv_nx + Mp * ld3, ld3, 0, 0);  // virtual rows are final for this layer
-      if (fuse_vs) {
+      if (fold_vs) {
+        // pass 1 only: the block is finished -- x, the p2v k|v and the next layer's time q|k|v of the virtual rows -- by the
+        // workgroups of the point<-virtual block below (MVT_ATTN_FRAME_CTX): one launch less on the serial chain
+        mvt_block_attn at{};
+        at.kind = MVT_ATTN_FRAME; at.S = S; at.n_keys = NV; at.heads = HEADS; at.dim_head = DH_; at.ldq = ld3; at.ldkv = ld3;
+        at.q = qv; at.k = qv + INNER; at.v = qv + 2 * INNER; at.defer_pass2 = 1;
+        MVT_TRY(mvt_attn_block_fused_bf16(vt, H_, &at, vs.out.w, vs.out.b, vs.fc1.w, vs.fc1.b, vs.fc2.w, vs.fc2.b, MLP, nx, nn, Mv, H_, split_ws,
+                                          stream));
+      } else if (fuse_vs) {
         // (pass 1 reads the virtual q|k|v; the p2v k|v projection that overwrites k|v is written by pass 2, a later launch)
         MVT_TRY(attn_block(vs, vt, Mv, MVT_ATTN_FRAME, qv, ld3, qv + INNER, qv + 2 * INNER, NV, nx, nn, split_ws));
       } else {
@@ -186,7 +196,17 @@ static int updater_run(const mvt_updater_weights* w, const float* x, int ldx, co
     // ---- point <- virtual cross attention, per frame
     {
       const mvt_block_next nx = last ? mvt_block_next{} : next_of(w->time_blk[i + 1].qkv, qkv_nx, ld3, 0, 0);
-      if (fuse_p2v && Mp >= 4096) {
+      if (fold_vs) {
+        mvt_block_ctx cx{};
+        cx.ws = split_ws; cx.chunks = MLP / 256; cx.b2 = vs.fc2.b; cx.x = vt; cx.ldx = H_;
+        cx.kv = next_of(p2v.kv, nullptr, ld3, 0, 0, p2v.ctx_ln_w, p2v.ctx_ln_b, 1e-5f);
+        if (!last) cx.next = next_of(w->time_blk[i + 1].qkv, qkv_nx + Mp * ld3, ld3, 0, 0);
+        mvt_block_attn at{};
+        at.kind = MVT_ATTN_FRAME_CTX; at.S = S; at.n_keys = NV; at.heads = HEADS; at.dim_head = DH_; at.ldq = INNER; at.ldkv = ld3;
+        at.q = qp; at.ctx = &cx;
+        MVT_TRY(mvt_attn_block_fused_bf16(tok, H_, &at, p2v.out.w, p2v.out.b, p2v.fc1.w, p2v.fc1.b, p2v.fc2.w, p2v.fc2.b, MLP, &nx, last ? 0 : 1,
+                                          Mp, H_, nullptr, stream));
+      } else if (fuse_p2v && Mp >= 4096) {
         MVT_TRY(attn_block(p2v, tok, Mp, MVT_ATTN_FRAME, qp, INNER, qv + INNER, qv + 2 * INNER, NV, &nx, last ? 0 : 1, nullptr));
       } else {
         MVT_TRY(mvt_attention_bf16(qp, INNER, 1, S, qv + INNER, qv + 2 * INNER, ld3, 1, S, att, INNER, S, n, NV, HEADS, DH_, BF, nullptr, stream));

@@ -558,7 +558,8 @@ ATTN_TIME, ATTN_FRAME = 1, 2
 class BlockAttn(C.Structure):
     """mvt_block_attn."""
     _fields_ = [("kind", C.c_int), ("S", C.c_int), ("n_keys", C.c_int), ("heads", C.c_int), ("dim_head", C.c_int), ("ldq", C.c_int),
-                ("ldkv", C.c_int), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("partials", C.c_void_p), ("n_splits", C.c_int)]
+                ("ldkv", C.c_int), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("partials", C.c_void_p), ("n_splits", C.c_int),
+                ("defer_pass2", C.c_int), ("ctx", C.c_void_p)]  # (the context form is only driven by the composite updater call)
 
 
 def attn_block_fused_bf16(x, ldx, kind, S, q, ldq, k, v, ldkv, n_keys, wo, bo, w1, b1, w2, b2, H, nexts, M, Cc, ws=None):

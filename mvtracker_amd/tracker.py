@@ -134,7 +134,7 @@ class MVTracker(nn.Module):
         self.bf16_store = os.environ.get("MVT_BF16_STORE", "1") != "0"  # bf16 mode: bf16 feature rows in the frame store
         # attention inside the block kernels: bit 0 time, bit 1 point<-virtual, bit 2 virtual self; bit 4: the virtual<-point block
         # combines the key-split partials in its prologue, no merge launch (all variants are bit-identical to the separate launches)
-        self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "23"))
+        self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "55"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
         self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
         self.encoder_streams = int(os.environ.get("MVT_ENC_STREAMS", "2"))  # 2: the chunks of an encoder call alternate between two streams

@@ -709,7 +709,7 @@ def test_updateformer_hidden_384_golden(golden, prec, tol):
     assert err < tol, err
 
 
-@pytest.mark.parametrize("n", [16, 1024, 37])
+@pytest.mark.parametrize("n", [16, 1024, 37, 400])
 def test_updater_fused_attention_matches_separate_launches(model, n):
     """Attention inside the block kernels (mvt_attn_block_fused_bf16: time / point<-virtual / virtual-self, partial merge in the
     block prologue) against the separate attention launches -- n = 1024 is the C3 shape (tiles straddling the point / virtual
@@ -718,13 +718,16 @@ def test_updater_fused_attention_matches_separate_launches(model, n):
     all key blocks instead of an online softmax; the time attention of a tile's tracks as ONE block-diagonal unit per head), so
     the outputs agree to bf16 rounding (a flipped rounding of one bf16 activation moves an output by ~1e-3 of its scale), not bit
     for bit; the bits that only move WHERE partials are combined (16) stay bit-identical.  The bar against the reference is
-    test_updateformer_bf16_vs_reference / test_refine_window_bf16_vs_reference_autocast."""
+    test_updateformer_bf16_vs_reference / test_refine_window_bf16_vs_reference_autocast.
+    Bit 5 (the virtual-self block's pass 2 inside the point<-virtual block, MVT_ATTN_FRAME_CTX; active from 4096 point rows:
+    n = 1024 and n = 400, the latter with a partial last tile and fewer tiles per frame) repeats pass 2's arithmetic in pass 2's
+    order: bit-identical to the same flags without it."""
     x = torch.randn(1, n, 12, 581, generator=torch.Generator().manual_seed(n)).to(DEV)
     outs = {}
     with _with_precision(model, "bf16"):
         old = model.fuse_attention
         try:
-            for f in (0, 1, 2, 4, 16, 23):
+            for f in (0, 1, 2, 4, 16, 23, 55, 39):
                 model.fuse_attention = f
                 outs[f] = model.update_former(x).clone()
             torch.cuda.synchronize()
@@ -732,6 +735,8 @@ def test_updater_fused_attention_matches_separate_launches(model, n):
             model.fuse_attention = old
     assert bool(torch.isfinite(outs[0]).all())
     assert torch.equal(outs[16], outs[0]), f"fuse_attention=16: max diff {(outs[16] - outs[0]).abs().max().item():.3e}"
+    assert torch.equal(outs[55], outs[23]), f"fuse_attention=55 vs 23: max diff {(outs[55] - outs[23]).abs().max().item():.3e}"
+    assert torch.equal(outs[39], outs[55]), f"fuse_attention=39 vs 55: max diff {(outs[39] - outs[55]).abs().max().item():.3e}"
     for f in (1, 2, 4, 23):
         rel = ((outs[f] - outs[0]).abs().max() / outs[0].abs().max()).item()
         mean = ((outs[f] - outs[0]).abs().mean() / outs[0].abs().mean()).item()
