@@ -61,8 +61,8 @@ __device__ unsigned long long mvt_stamp_buf[2 * 8 * 64];
     unsigned long long t_;                                                                                        \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
-    if (lane == 0 && MVT_STAMP_SEL && (blockIdx.x == 0 || blockIdx.x == MVT_STAMP_WG1) && blockIdx.y == 0 && blockIdx.z == 0) \
-      mvt_stamp_buf[((blockIdx.x ? 1 : 0) * 8 + wave) * 64 + (i)] = t_;                                           \
+    if (lane == 0 && MVT_STAMP_SEL && (bx == 0 || bx == MVT_STAMP_WG1) && by == 0 && bz == 0) /* (logical block indices) */ \
+      mvt_stamp_buf[((bx ? 1 : 0) * 8 + wave) * 64 + (i)] = t_;                                                   \
   } while (0)
 #else
 #define STAMP(i) \
@@ -70,10 +70,11 @@ __device__ unsigned long long mvt_stamp_buf[2 * 8 * 64];
   } while (0)
 #endif
 
-#ifdef MVT_STAMPS
+#if defined(MVT_STAMPS) && defined(MVT_ASTAMPS)  // (stamps inside attn_compute: only with the default MVT_STAMP_SEL)
 #define ASTAMP(i)                                       \
   do {                                                  \
     const int wave = threadIdx.x >> 6;                  \
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z; \
     STAMP(i);                                           \
   } while (0)
 #else
@@ -601,8 +602,10 @@ template <int NMB, int MODE, int ATT>
 __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   using K_ = Cfg<NMB>;
   constexpr int BM = K_::BM, HC = K_::HC, LDH = K_::LDH, LDA = K_::LDA;
-  constexpr bool CTX = ATT == 6;  // ATT 2 with the context k|v derived in the kernel (deferred pass 2 of the context block)
-  static_assert(!CTX || (NMB == 2 && MODE == 0), "the context form runs on the 64-row tiles of the point rows");
+  // ATT 6: ATT 2 on the 64-row point tiles with the attention's context (the virtual tokens' k|v) derived in the kernel from a
+  // DEFERRED pass 2 (step 0 below)
+  constexpr bool CTX = ATT == 6;
+  static_assert(!CTX || (NMB == 2 && MODE == 0), "ATT 6 runs on the 64-row tiles of the point rows");
   // (ATT 6: the H buffers also hold the context's k|v tile [64][LDKV] during the prologue -- 74.8 KB instead of 67.6)
   constexpr int HSZ = CTX && (64 * LDKV + 1) / 2 > BM * LDH ? (64 * LDKV + 1) / 2 : BM * LDH;
   __shared__ __attribute__((aligned(16))) unsigned short Xs[BM * LDX];
@@ -613,25 +616,42 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int r = lane & 31, h = lane >> 5;
+  // Logical block indices.  The frame-major grids (x = token tile, y = MLP chunk / column slice, z = frame) are placed XCD-AWARE:
+  // the hardware deals consecutive linear workgroup ids round-robin to the 8 XCDs, so with the plain mapping every XCD works on every
+  // frame and pulls every frame's hand-over data (split-path partial sums, attention partials, k|v rows -- all written by OTHER
+  // XCDs in the previous launch) through the fabric into its own L2: 3.9 MB of partial sums per XCD and launch instead of 0.65 MB.
+  // Remapped, XCD c owns the contiguous run [c, c+1) * total/8 of the frame-major order: 1.5 frames at S = 12, the same frames in
+  // every kernel of the chain.
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+  if constexpr (ATT == 2 || ATT == 3 || ATT == 5 || ATT == 6) {  // (the frame-major forms, FM below)
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    if (total % 8 == 0) {
+      const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const unsigned V = (L % 8) * (total / 8) + L / 8;
+      bx = (int)(V % gridDim.x);
+      by = (int)((V / gridDim.x) % gridDim.y);
+      bz = (int)(V / (gridDim.x * gridDim.y));
+    }
+  }
   static_assert(ATT == 0 || ATT == 5 || MODE != 2, "pass 2 of the split path has no attention");
   static_assert(ATT != 5 || MODE == 2, "ATT 5 = pass 2 on the frame-major tiles of an ATT 2 / ATT 3 pass 1");
   static_assert((MODE != 1 && MODE != 2) || NMB == 1, "the split path runs on 32-row tiles");
-  constexpr bool FM = ATT == 2 || ATT == 3 || ATT == 5 || ATT == 6;  // frame-major tile: tokens blockIdx.x*BM.. of frame blockIdx.z
+  constexpr bool FM = ATT == 2 || ATT == 3 || ATT == 5 || ATT == 6;  // frame-major tile: tokens bx*BM.. of frame bz
   const int bmv = ATT == 1 ? p.bmv : BM;                      // rows of the tile that hold tokens
-  const long long m0 = FM ? 0 : (long long)blockIdx.x * bmv;
+  const long long m0 = FM ? 0 : (long long)bx * bmv;
   const long long ntok = FM ? p.M / p.S : 0;                   // tokens per frame
   // global row of tile row i (-1: none)
   auto grow = [&](int i) -> long long {
     if (FM) {
-      const long long tk = (long long)blockIdx.x * BM + i;
-      return tk < ntok ? tk * p.S + (long long)blockIdx.z : -1;
+      const long long tk = (long long)bx * BM + i;
+      return tk < ntok ? tk * p.S + (long long)bz : -1;
     }
     const long long m = m0 + i;
     return (i < bmv && m < p.M) ? m : -1;
   };
   // rows [rlo, rhi) bound the tile (workgroup-uniform)
-  const long long rlo = FM ? (long long)blockIdx.x * BM * p.S : m0;
-  const long long rhi = FM ? ((long long)blockIdx.x * BM + BM) * p.S : m0 + bmv;
+  const long long rlo = FM ? (long long)bx * BM * p.S : m0;
+  const long long rhi = FM ? ((long long)bx * BM + BM) * p.S : m0 + bmv;
   constexpr bool HAS_MLP = MODE == 0 || MODE == 1;  // MODE 2: pass 2 of the split path; MODE 3: LayerNorm + projections of a
                                                     // read-only x in whole 64-row tiles (mvt_ln_proj_bf16 at large M)
   if (HAS_MLP)
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   // layout itself, so that pass 1's stores and pass 2's loads are contiguous 1-KiB pieces per wave instruction (as [M][C] rows
   // every access of a wave touched 32 different rows and pass 2 spent half its time on these loads).  Both passes use the same
   // tiling (grid.x, grid.z), hence the same (tile, wave, g, lane) <-> element map.
-  const long long ws_tile = FM ? (long long)blockIdx.z * gridDim.x + blockIdx.x : (long long)blockIdx.x;
+  const long long ws_tile = FM ? (long long)bz * gridDim.x + bx : (long long)bx;
   const long long ws_ntile = FM ? (long long)gridDim.z * gridDim.x : (long long)gridDim.x;
   auto ws_off = [&](int chunk, int g) -> long long { return ((((long long)chunk * ws_ntile + ws_tile) * 8 + wave) * 4 + g) * 256 + lane * 4; };
   // a projection runs in this workgroup when its row range meets the workgroup's rows (workgroup-uniform)
@@ -657,16 +677,19 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   const bool outp = MODE != 2 && ATT != 4 && (ATT != 0 || p.att != nullptr);
   const unsigned short* wo_row = p.wo + ((long long)wave * 18 * 64 + lane) * 8;
   const unsigned short* fc1_first = p.w1 + ((long long)(wave % K_::JW) * (C / 16) * 64 + lane) * 8 +
-                                    (long long)(MODE == 1 ? (int)blockIdx.y : 0) * K_::JW * (C / 16) * FS;
+                                    (long long)(MODE == 1 ? by : 0) * K_::JW * (C / 16) * FS;
   auto prefetch_wo = [&]() { fill_wq(wq, wo_row); };
   if (HAS_MLP && !outp) {
     fill_wq(wq, fc1_first);
   } else if (CTX) {
-    // (the queue starts with the context's k|v projection, requested below once the partial sums' registers are free)
+    // the queue starts with the context's k|v projection (18 column blocks, every wave has a first one), requested ahead of
+    // the partial sums: the first barrier of step 0 (a __syncthreads waits for EVERY outstanding load) then finds it resident --
+    // requested after the sums, the fragments' whole memory round trip sat in front of that barrier (in-kernel stamps: 6-9 k cycles)
+    fill_wq(wq, p.c_kv.w + ((long long)wave * (C / 16) * 64 + lane) * 8);
   } else if (outp) {
     prefetch_wo();
   } else if (EARLY && MODE == 2) {
-    const int nb0e = (int)blockIdx.y * 8 + wave;
+    const int nb0e = by * 8 + wave;
     if (active(0) && nb0e < (p.next[0].N + 31) / 32) {
       fill_wq(wq, p.next[0].w + ((long long)nb0e * (C / 16) * 64 + lane) * 8);
       early_have = true;
@@ -712,31 +735,36 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   // workgroups of the frame evaluate the optional further projection of the context rows (the next layer's time q|k|v), 8 column
   // blocks each.
   if constexpr (CTX) {
+    constexpr int KVB = 2 * 288 / 32;  // column blocks of the projection: k | v
     unsigned short* KV = &Hs[0][0];
-    for (int i = t; i < 2 * 288; i += NT) cbs[i] = p.c_kv.b[i];
+    unsigned short* XN = &Xs[0];  // the 64 normalised context rows (the GEMM's activation operand)
+    for (int i = t; i < KVB * 32; i += NT) cbs[i] = p.c_kv.b[i];
     const long long ctile = 2LL * gridDim.z;
     auto cws_off = [&](int chunk, int mb, int g) -> long long {
-      return ((((long long)chunk * ctile + (long long)blockIdx.z * 2 + mb) * 8 + wave) * 4 + g) * 256 + lane * 4;
+      return ((((long long)chunk * ctile + (long long)bz * 2 + mb) * 8 + wave) * 4 + g) * 256 + lane * 4;
     };
     constexpr int MAXCH = 4;
     const int nch = p.c_nch;
     f32x16 cv[2];
-    {
-      f32x4 part[2][4][MAXCH + 1], b2v[4];
+    // (two halves of the channel quads: 80 registers of loads in flight each, next to the 64 of the weight queue -- the transfer is
+    //  bound by the CU's 64 B / clk from L2, 320 KB per workgroup, not by the number of loads in flight)
+#pragma unroll
+    for (int gh = 0; gh < 2; ++gh) {
+      f32x4 part[2][2][MAXCH + 1], b2v[2];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
           for (int sidx = 0; sidx <= MAXCH; ++sidx)
-            part[mb][g][sidx] = sidx <= nch ? *reinterpret_cast<const f32x4*>(p.c_ws + cws_off(sidx, mb, g)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            part[mb][g][sidx] = sidx <= nch ? *reinterpret_cast<const f32x4*>(p.c_ws + cws_off(sidx, mb, 2 * gh + g)) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) b2v[g] = *reinterpret_cast<const f32x4*>(p.c_b2 + wave * 32 + 8 * g + 4 * h);
-      __builtin_amdgcn_sched_barrier(0);  // (all loads ahead of the first add)
+      for (int g = 0; g < 2; ++g) b2v[g] = *reinterpret_cast<const f32x4*>(p.c_b2 + wave * 32 + 8 * (2 * gh + g) + 4 * h);
+      __builtin_amdgcn_sched_barrier(0);  // (all loads of the half ahead of its first add)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 2; ++g) {
           f32x4 xv = part[mb][g][0];
 #pragma unroll
           for (int sidx = 1; sidx <= MAXCH; ++sidx)
@@ -745,16 +773,17 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
               for (int e = 0; e < 4; ++e) xv[e] += part[mb][g][sidx][e];
             }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) cv[mb][4 * g + e] = 0.f + (xv[e] + b2v[g][e]);  // (pass 2 accumulates into a zero: same bits)
+          for (int e = 0; e < 4; ++e) cv[mb][4 * (2 * gh + g) + e] = 0.f + (xv[e] + b2v[g][e]);  // (pass 2 accumulates into a zero: same bits)
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    STAMP(56);
     auto krow_w = [&](int nb) { return p.c_kv.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
     auto nrow_w = [&](int nb) { return p.c_next.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
-    fill_wq(wq, krow_w(wave));  // (18 column blocks: every wave has a first one)
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        const long long m = (long long)(mb * 32 + r) * p.S + (long long)blockIdx.z;
+        const long long m = (long long)(mb * 32 + r) * p.S + (long long)bz;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 o;
@@ -765,12 +794,12 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
     }
     float cms[2][2];
-    ln_to_lds<2>(cv, Xs, st, wave, lane, p.c_kv.eps, p.c_kv.lnw, p.c_kv.lnb, cms, false);
+    ln_to_lds<2>(cv, XN, st, wave, lane, p.c_kv.eps, p.c_kv.lnw, p.c_kv.lnb, cms, false);
+    STAMP(57);
     const int nnb = p.c_next.w ? (p.c_next.N + 31) / 32 : 0;
-    const bool do_next = (int)blockIdx.x * 8 < nnb;  // (workgroup-uniform)
-    const int nbn = (int)blockIdx.x * 8 + wave;
+    const bool do_next = bx * 8 < nnb;  // (workgroup-uniform)
+    const int nbn = bx * 8 + wave;
     const bool my_next = nbn < nnb;
-    constexpr int KVB = 2 * 288 / 32;
 #pragma unroll 1
     for (int nb = wave; nb < KVB; nb += 8) {
       f32x16 acc[2];
@@ -778,7 +807,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
-      gemm_wq<C / 16, 2>(acc, wq, krow_w(nb), nb + 8 < KVB ? krow_w(nb + 8) : (my_next ? nrow_w(nbn) : wo_row), &Xs[r * LDX + 8 * h], LDX, 0);
+      gemm_wq<C / 16, 2>(acc, wq, krow_w(nb), nb + 8 < KVB ? krow_w(nb + 8) : (my_next ? nrow_w(nbn) : wo_row), &XN[r * LDX + 8 * h], LDX, 0);
+      const int kc = nb * 32;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -786,23 +816,24 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = acc[mb][4 * g + e] + cbs[nb * 32 + 8 * g + 4 * h + e];
-          *reinterpret_cast<u32x2*>(&KV[(mb * 32 + r) * LDKV + nb * 32 + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, __builtin_convertvector(o, bf16x4));
+          *reinterpret_cast<u32x2*>(&KV[(mb * 32 + r) * LDKV + kc + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, __builtin_convertvector(o, bf16x4));
         }
     }
+    STAMP(58);
     if (do_next) {
       __syncthreads();  // every wave is done reading Xs; st (the statistics scratch) is idle: it carries the projection's bias
       for (int i = t; i < p.c_next.N; i += NT) st[i] = p.c_next.b[i];
-      ln_to_lds<2>(cv, Xs, st, wave, lane, p.c_next.eps, p.c_next.lnw, p.c_next.lnb, cms, true);
+      ln_to_lds<2>(cv, XN, st, wave, lane, p.c_next.eps, p.c_next.lnw, p.c_next.lnb, cms, true);
       if (my_next) {
         f32x16 acc[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
-        gemm_wq<C / 16, 2>(acc, wq, nrow_w(nbn), wo_row, &Xs[r * LDX + 8 * h], LDX, 0);
+        gemm_wq<C / 16, 2>(acc, wq, nrow_w(nbn), wo_row, &XN[r * LDX + 8 * h], LDX, 0);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-          const long long m = (long long)(mb * 32 + r) * p.S + (long long)blockIdx.z;
+          const long long m = (long long)(mb * 32 + r) * p.S + (long long)bz;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n = nbn * 32 + 8 * g + 4 * h;
@@ -821,6 +852,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
       __syncthreads();  // st is about to become the attention's zero row
     }
+    STAMP(59);
     // (the barrier that publishes the k|v tile and frees Xs is the one at the head of the attention phase below)
   }
 
@@ -932,15 +964,15 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
   } else if (MODE != 2 && ATT == 3) {
     // The attention tile from the key-split partials of the virtual<-point attention (one (m, l, O^T) state per split and
     // (frame, head) chunk, in attention_mfma_kernel's accumulator layout).  The tile is frame-major -- the 32 virtual tokens
-    // mb = blockIdx.x of frame blockIdx.z -- so wave hd reads the records of its (frame, head) chunk in their NATIVE lane layout
+    // mb = bx of frame bz -- so wave hd reads the records of its (frame, head) chunk in their NATIVE lane layout
     // (lane (r, h): query mb*32 + r, rows d = db*32 + (e&3) + 8(e>>2) + 4h) and combines the splits with the same sequential
     // arithmetic, in the same order, as attention_merge_kernel -- which this replaces: bit-identical results.
     unsigned short* As = &Hs[0][0];
     static_assert(ATT != 3 || NMB == 1, "partials tiles are 32 tokens");
     if (wave < 6) {
-      const int mb = (int)blockIdx.x;
+      const int mb = bx;
       const long long nchunk = (long long)p.S * 6;
-      const long long cid = (long long)blockIdx.z * 6 + wave;
+      const long long cid = (long long)bz * 6 + wave;
       // the records of ALL splits are requested before the first is combined (they were written by other CUs: as a load-combine
       // loop over the splits every iteration paid its own trip to the memory side); MVT_ATTN_NSPLIT splits at most
       constexpr int MAXS = MVT_ATTN_NSPLIT;
@@ -1035,9 +1067,9 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
       }
     } else {
       const bool on = wave < 6 && grow(0) >= 0;
-      const long long left = ntok - (long long)blockIdx.x * BM;
+      const long long left = ntok - (long long)bx * BM;
       const int nq = left < BM ? (int)left : BM;
-      auto qrow = [&](int i) { return ((long long)blockIdx.x * BM + i) * p.S + (long long)blockIdx.z; };
+      auto qrow = [&](int i) { return ((long long)bx * BM + i) * p.S + (long long)bz; };
       AttnFrags<NMB, 2> fr;
       if (CTX) {
         // k|v of the frame's context tokens from the LDS tile of step 0 (tile row = context token); the tile lives where the
@@ -1047,7 +1079,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         if (on) attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, KV, KV + 288, LDKV, krow, p.nkeys, wave, lane);
         __syncthreads();
       } else {
-        auto krow = [&](int j) { return (long long)j * p.S + (long long)blockIdx.z; };
+        auto krow = [&](int j) { return (long long)j * p.S + (long long)bz; };
         if (on) attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, lane);
       }
       if (on) attn_compute<NMB, 2>(fr, nq, p.nkeys, wave, vt, zrow, As, LDA, 0, lane, 0, vstride);
@@ -1170,7 +1202,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     // ONE fragment queue for the whole MLP: the wave consumes fc1(c0), fc2(c0), fc1(c1), ... strictly in this order, 16
     // k-steps each, so the queue always holds the next 16 fragments of that sequence (>= 16 MFMA k-steps of lookahead,
     // which is what an L2 round trip needs; two half-depth queues left every fragment ~250 cycles short)
-    const int c_lo = MODE == 1 ? (int)blockIdx.y : 0, c_hi = MODE == 1 ? c_lo + 1 : nchunk;
+    const int c_lo = MODE == 1 ? by : 0, c_hi = MODE == 1 ? c_lo + 1 : nchunk;
     // (the queue already holds fc1(c_lo): filled at kernel start, or by the output projection while it ran)
 #pragma unroll 1
     for (int c = c_lo; c < c_hi; ++c) {
@@ -1228,8 +1260,8 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
             a4[e] = acc2[mb][4 * g + e];
             x4[e] = v[mb][4 * g + e];
           }
-          *reinterpret_cast<f32x4*>(p.ws + ws_off((int)blockIdx.y + 1, g)) = a4;
-          if (blockIdx.y == 0) *reinterpret_cast<f32x4*>(p.ws + ws_off(0, g)) = x4;
+          *reinterpret_cast<f32x4*>(p.ws + ws_off(by + 1, g)) = a4;
+          if (by == 0) *reinterpret_cast<f32x4*>(p.ws + ws_off(0, g)) = x4;
         }
       }
       return;
@@ -1243,7 +1275,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         for (int e = 0; e < 4; ++e) v[mb][4 * g + e] += acc2[mb][4 * g + e] + p.b2[wave * 32 + 8 * g + 4 * h + e];
   }
   STAMP(30);
-  if (MODE == 0 || ATT == 4 || (p.ws && blockIdx.y == 0)) store_x();  // (never in the projection-only form: x is read-only there)
+  if (MODE == 0 || ATT == 4 || (p.ws && by == 0)) store_x();  // (never in the projection-only form: x is read-only there)
   STAMP(31);
 
   // ---- 3. optional follow-up projections: y_i = LayerNorm_i(x) . Wn_i^T + bn_i
@@ -1264,7 +1296,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     STAMP(33 + 8 * q);
     const int nblocks = (nx.N + 31) / 32;
     auto nrow_of = [&](int nb) { return nx.w + ((long long)nb * (C / 16) * 64 + lane) * 8; };
-    const int nb0 = MODE == 2 ? (int)blockIdx.y * 8 + wave : wave, nbstep = MODE == 2 ? 8 * (int)gridDim.y : 8;
+    const int nb0 = MODE == 2 ? by * 8 + wave : wave, nbstep = MODE == 2 ? 8 * (int)gridDim.y : 8;
     if (nb0 < nblocks && !have) fill_wq(wq, nrow_of(nb0));
     // after this wave's last block the queue moves on to its first block of the next projection, if that one runs here
     const int qn = q + 1 < MVT_BLOCK_MAX_NEXT ? q + 1 : MVT_BLOCK_MAX_NEXT - 1;

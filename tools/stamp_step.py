@@ -34,6 +34,7 @@ buf = np.zeros(2 * 8 * 64, dtype=np.uint64)
 assert lib.mvt_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 buf = buf.reshape(2, 8, 64).astype(np.int64)
 names = {0: "start", 1: "pre-attn", 2: "tile staged", 3: "barrier", 4: "out-proj", 5: "x added", 6: "LN1", 30: "mlp end", 31: "store x", 63: "end"}
+names.update({56: "ctx summed", 57: "ctx LN", 58: "ctx proj", 59: "ctx next"})
 for c in range(4):
     names.update({8 + 5 * c: f"c{c} begin", 9 + 5 * c: f"c{c} fc1", 10 + 5 * c: f"c{c} gelu+st", 11 + 5 * c: f"c{c} barrier", 12 + 5 * c: f"c{c} fc2"})
 for q in range(3):
