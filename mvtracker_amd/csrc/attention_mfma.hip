@@ -57,7 +57,24 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
 
   const int chunks = (nq + 63) / 64;
   const long long nchunk = (long long)groups * heads * chunks;
-  const long long chunk_id = KS == 1 ? (long long)blockIdx.x * 4 + wave : (long long)blockIdx.x;
+  // Key-split-over-workgroups form (ws != null): placed XCD-AWARE.  The hardware deals consecutive linear workgroup ids round-robin
+  // to the 8 XCDs; chunk = (frame, head), so with the plain mapping the six heads of a frame -- which share every 128-byte line of
+  // the frame's K / V rows -- sit on six different XCDs and each pulls those rows through the fabric into its own L2.  Remapped, XCD c
+  // owns the chunk-major run [c, c+1) * total/8: whole frames (the same frames as in the block kernels that produced K / V's
+  // consumers' inputs and that read the partial records next, block_fused.hip).
+  unsigned bxl = blockIdx.x, byl = blockIdx.y;
+#ifndef MVT_ATTN_NO_XCD  // (A/B builds, tools/build_variant.sh)
+  if (KS > 1 && ws) {
+    const unsigned total = gridDim.x * gridDim.y;
+    if (total % 8 == 0) {
+      const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+      const unsigned V = (L % 8) * (total / 8) + L / 8;
+      bxl = V / gridDim.y;
+      byl = V % gridDim.y;
+    }
+  }
+#endif
+  const long long chunk_id = KS == 1 ? (long long)bxl * 4 + wave : (long long)bxl;
   const bool chunk_ok = chunk_id < nchunk;
   const long long cid = chunk_ok ? chunk_id : 0;
   const int qc = (int)(cid % chunks);
@@ -66,7 +83,7 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
 
   const int nkb = (nk + 31) / 32;                       // key blocks
   const int gper = ws ? (nkb + (int)gridDim.y - 1) / (int)gridDim.y : nkb;   // ... of this workgroup
-  const int g0 = ws ? (int)blockIdx.y * gper : 0;
+  const int g0 = ws ? (int)byl * gper : 0;
   const int g1 = g0 + gper < nkb ? g0 + gper : nkb;
   const int per = (gper + KS - 1) / KS;
   const int kb0 = KS == 1 ? g0 : g0 + wave * per;
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(KS == 1 ? 256 : KS * 64) void attention_mfma_kernel
   if (!chunk_ok) return;
   if (ws) {
     {
-      const long long rec = blockIdx.y * nchunk + chunk_id;
+      const long long rec = byl * nchunk + chunk_id;
       *reinterpret_cast<f32x4*>(ws + mvt_part_off(rec, 0, lane)) = (f32x4){m[0], m[1], l[0], l[1]};
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)

@@ -193,10 +193,19 @@ __device__ __forceinline__ void knn_scan_body(unsigned long long* lds, const flo
                                               int nseg, unsigned long long* __restrict__ keys, int qgroups,
                                               const int* __restrict__ seed_idx, int seed_k, int seed_cw, int seed_ch, int seed_fw,
                                               int seed_fh, const float* __restrict__ box, int grid_w, int grid_h,
-                                              int* __restrict__ idx_direct = nullptr, const float* __restrict__ gbox = nullptr) {
+                                              int* __restrict__ idx_direct = nullptr, const float* __restrict__ gbox = nullptr,
+                                              bool xcd_frames = false) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // task id -> (segment, query group, slot); segment fastest so that heavy frames spread over CUs  (32-bit: the launchers bound it)
-  const unsigned task = blockIdx.x * 4u + (unsigned)wave;
+  // xcd_frames (the seeded all-level search, every frame equally heavy): tasks are slot-major, so a contiguous run of blocks is a
+  // run of whole frames -- XCD c (the hardware deals consecutive block ids round-robin to the 8 XCDs) takes the run [c, c+1) *
+  // gridDim.x / 8 and keeps ITS 1.5 frames' point clouds and tile boxes (1.3 MB per frame over the four levels) in its own 4 MB
+  // L2, instead of all 8 XCDs cycling all S frames (16 MB at S = 12) through theirs.
+  unsigned bxr = blockIdx.x;
+#ifndef MVT_KNN_NO_XCD  // (A/B builds)
+  if (xcd_frames && gridDim.x % 8 == 0) bxr = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+#endif
+  const unsigned task = bxr * 4u + (unsigned)wave;
   const unsigned ntask = (unsigned)qgroups * (unsigned)S * (unsigned)nseg;
   if (task >= ntask) return;
   const unsigned tq = task / (unsigned)nseg;
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256) void knn_search_levels_kernel(KnnLevels a, con
   __shared__ unsigned long long lds[4 * Q * CAP];
   const mvt_knn_level L = a.lv[blockIdx.y];
   knn_scan_body<Q>(lds, L.xyz, L.P, coords, N, S, frame0, frame_step, T, K, 1, nullptr, qgroups, L.seed_idx, seed_k, 0, 0, 0, 0, L.tile_box,
-                   L.grid_w, L.grid_h, L.idx_out, L.group_box);
+                   L.grid_w, L.grid_h, L.idx_out, L.group_box, true);
 }
 
 // Merge the nseg per-segment lists of one (track, slot) into its K nearest neighbour indices.  Every lane holds
