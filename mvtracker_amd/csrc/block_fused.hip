@@ -26,6 +26,20 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Workgroup barrier that orders LDS only.  The waves of a workgroup exchange data through LDS alone, so a barrier has to wait for
+// the wave's LDS operations -- not, as __syncthreads() does (s_waitcnt vmcnt(0) lgkmcnt(0) before s_barrier), for every global load
+// in flight: the 16 weight fragments of the queue, the tile's x rows and the affine parameters are requested ahead of barriers on
+// purpose, and draining them at each one put their memory round trips back on the critical path.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef MVT_FULL_BARRIERS  // (A/B builds)
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
 constexpr int NT = 512;   // threads (8 waves)
 constexpr int C = 256;    // hidden size of the updater
 constexpr int LDX = C + 8;
@@ -552,7 +566,7 @@ __device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short
         st[(wave * BM + mb * 32 + r) * 2 + 1] = s2;
       }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
       float s1 = 0.f, s2 = 0.f;
@@ -583,7 +597,7 @@ __device__ __forceinline__ void ln_to_lds(const f32x16 (&v)[NMB], unsigned short
       *reinterpret_cast<u32x2*>(&Xs[(mb * 32 + r) * LDX + n]) = __builtin_bit_cast(u32x2, b);
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // MODE 0: the whole block in one workgroup per row tile.
@@ -821,7 +835,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     }
     STAMP(58);
     if (do_next) {
-      __syncthreads();  // every wave is done reading Xs; st (the statistics scratch) is idle: it carries the projection's bias
+      lds_barrier();  // every wave is done reading Xs; st (the statistics scratch) is idle: it carries the projection's bias
       for (int i = t; i < p.c_next.N; i += NT) st[i] = p.c_next.b[i];
       ln_to_lds<2>(cv, XN, st, wave, lane, p.c_next.eps, p.c_next.lnw, p.c_next.lnb, cms, true);
       if (my_next) {
@@ -850,7 +864,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
           }
         }
       }
-      __syncthreads();  // st is about to become the attention's zero row
+      lds_barrier();  // st is about to become the attention's zero row
     }
     STAMP(59);
     // (the barrier that publishes the k|v tile and frees Xs is the one at the head of the attention phase below)
@@ -868,7 +882,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       const int k0 = half ? KSA * 16 : 0, kq = (half ? KSB : KSA) * 4;  // float4 per row of this half
-      if (half) __syncthreads();  // every wave is done with the first half
+      if (half) lds_barrier();  // every wave is done with the first half
       if (p.tokx) {
         for (int f = t; f < BM * kq; f += NT) {
           const int row = f / kq, c = (f - row * kq) * 4;
@@ -944,7 +958,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
       }
       STAMP(1 + 4 * half);
-      __syncthreads();
+      lds_barrier();
       STAMP(2 + 4 * half);
       if (half == 0) gemm_wt<KSA, NMB>(v, p.win + ((long long)wave * (KSA + KSB) * 64 + lane) * 8, &As[r * LDT + 8 * h], LDT, 0);
       else gemm_wt<KSB, NMB>(v, p.win + (((long long)wave * (KSA + KSB) + KSA) * 64 + lane) * 8, &As[r * LDT + 8 * h], LDT, 0);
@@ -1030,7 +1044,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
     }
     pre_gemm();
-    __syncthreads();
+    lds_barrier();
     gemm_wq18<NMB, HAS_MLP>(v, wq, wx, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
@@ -1050,7 +1064,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     unsigned short* vt = wave < XWV ? &Xs[wave * VPW * VTA] : &Hs[0][0] + ((BM * LDA + 7) & ~7) + (wave - XWV) * VPW * VTA;
     constexpr int vstride = VPW == 2 ? VTA : 0;
     static_assert(XWV + ((2 * BM * LDH - BM * LDA - 8) / VTA) / VPW >= 6, "the V^T images of six waves fit beside the attention tile");
-    __syncthreads();
+    lds_barrier();
     STAMP(1);
     if (ATT == 1) {
       // Time attention of the tile's whole tracks (rows track-major: row = track * S + frame): one BLOCK-DIAGONAL unit per head --
@@ -1077,7 +1091,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         const unsigned short* KV = &Hs[0][0];
         auto krow = [&](int j) { return (long long)j; };
         if (on) attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, KV, KV + 288, LDKV, krow, p.nkeys, wave, lane);
-        __syncthreads();
+        lds_barrier();
       } else {
         auto krow = [&](int j) { return (long long)j * p.S + (long long)bz; };
         if (on) attn_load<NMB, 2>(fr, p.aq, p.ldaq, qrow, nq, p.ak, p.av, p.ldakv, krow, p.nkeys, wave, lane);
@@ -1086,7 +1100,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     }
     pre_gemm();
     STAMP(2);
-    __syncthreads();
+    lds_barrier();
     STAMP(3);
     gemm_wq18<NMB, HAS_MLP>(v, wq, wx, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
@@ -1113,7 +1127,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     }
     pre_gemm();
     STAMP(2);
-    __syncthreads();
+    lds_barrier();
     STAMP(3);
     gemm_wq18<NMB, HAS_MLP>(v, wq, wx, fc1_first, &As[r * LDA + 8 * h], LDA);
 #pragma unroll
@@ -1239,7 +1253,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
         }
       }
       STAMP(10 + 5 * c);
-      __syncthreads();
+      lds_barrier();
       STAMP(11 + 5 * c);
       // fc2 partial: out^T block (channels of this wave) += W2[:, chunk] . H^T; refills the queue with the next chunk's fc1
       // fragments (after the last chunk: with the first follow-up projection's, or harmlessly with fc1(c0) again)
@@ -1286,7 +1300,7 @@ __global__ __launch_bounds__(NT) void block_fused_bf16(BlockArgs p) {
     if (q >= p.n_next) break;
     if (!active(q)) continue;  // (have is false here: a chain is only set up towards an active projection)
     const mvt_block_next nx = p.next[q];
-    __syncthreads();  // every wave is done reading Xs / Hs
+    lds_barrier();  // every wave is done reading Xs / Hs
     // the projection's bias goes through LDS (b1s is free after the MLP; N <= 4C): a global load in the epilogue would sit
     // behind the 16 queued fragment loads in the in-order vmcnt counter and expose their whole latency every block
     for (int i = t; i < nx.N; i += NT) b1s[i] = nx.b[i];
