@@ -116,7 +116,9 @@ static int updater_run(const mvt_updater_weights* w, const float* x, int ldx, co
   };
   const bool fuse_time = (w->fuse_attention & 1) && S <= 32, fuse_p2v = (w->fuse_attention & 2) != 0, fuse_vs = (w->fuse_attention & 4) != 0;
   // bit 5: the virtual-self block's pass 2 runs inside the point<-virtual block (needs both attentions in their block kernels)
-  const bool fold_vs = (w->fuse_attention & 32) && fuse_p2v && fuse_vs && (long long)n * S >= 4096 && MLP / 256 <= 4;
+  // (the first workgroups of a frame also evaluate the next layer's time q|k|v of the virtual rows, 8 column blocks each: enough tiles)
+  const bool fold_vs = (w->fuse_attention & 32) && fuse_p2v && fuse_vs && (long long)n * S >= 4096 && MLP / 256 <= 4 &&
+                       8 * ((n + 63) / 64) >= (3 * INNER + 31) / 32;
 
   // tokens: input transform of the point rows, learned virtual tokens repeated over the S frames (blocks.py:456-459), and the
   // first time-attention q|k|v projection -- one launch when the fragment-major input weights are available
