@@ -523,6 +523,11 @@ typedef struct mvt_encoder_weights {
 long long mvt_encoder_workspace_bytes(int n, int H, int W, int latent_dim); /* host; -1 on bad arguments */
 int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4, int n, int H, int W, void* out_rows, int ldo, int out_bf16,
                         void* workspace, long long workspace_bytes, void* stream);
+/* ... the same with the stem reading the clip's planar frames itself: rgbs (V,T,3,H,W) in [0, 255], fp32 or (is_u8) uint8; the n images
+ * img0 .. img0 + n - 1 in frame-major numbering (image t * V + v = view v of frame t); normalised on load exactly as mvt_rgb_*_to_nhwc4
+ * does (2 (x / 255) - 1, mvtracker.py:455) -- bit-identical results without the [n][H][W][4] staging tensor and its launch. */
+int mvt_encoder_forward_rgb(const mvt_encoder_weights* w, const void* rgbs, int is_u8, int V, int T, long long img0, int n, int H, int W,
+                            void* out_rows, int ldo, int out_bf16, void* workspace, long long workspace_bytes, void* stream);
 
 /* mvt_updateformer_forward with the 581-wide token rows ASSEMBLED inside its first kernel (mvt_token_input_proj_bf16: the
  * arithmetic of mvt_token_assemble) instead of read from a token matrix: one refinement iteration after the correlation is then

@@ -51,6 +51,12 @@ struct RowsArgs {
   const float* in_stats;  // [n][Cin][2] or null
   float* out_part;        // [n][slots][Cout][2] or null
   int H, W, Cin, Cout, ldw, ldo, slots, in_bf16, out_bf16;
+  // stem only: the input is read straight from the clip's planar frames (V,T,3,H,W), fp32 or uint8 in [0, 255] -- image i of the call is
+  // view (rgb_img0 + i) % V of frame (rgb_img0 + i) / V -- and normalised on the way (2 (x / 255) - 1, mvtracker.py:455; the
+  // arithmetic of rgb_to_nhwc4_kernel, whose [n][H][W][4] fp32 staging tensor and launch this replaces)
+  const void* rgb;
+  int rgb_u8, rgb_V, rgb_T;
+  long long rgb_img0;
 };
 
 constexpr int TR = 8;            // output rows per workgroup (stem and the stride-1 3x3 kernels)
@@ -606,6 +612,13 @@ __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
   const long long img = b / tiles_y;
   const int y0 = ty * TR, x0 = tx * TC;
   const float* in = p.in + img * (long long)p.H * p.W * 4;
+  const long long hw = (long long)p.H * p.W;
+  long long plane0 = 0;  // first element of the image's R plane in the planar clip
+  if (p.rgb) {
+    const long long gi = p.rgb_img0 + img;
+    const long long tt = gi / p.rgb_V, vv = gi - tt * p.rgb_V;
+    plane0 = ((vv * p.rgb_T + tt) * 3) * hw;
+  }
 
   f32x4 rp[NPL];
 #pragma unroll
@@ -615,7 +628,21 @@ __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
     const int gy = 2 * y0 - 3 + py, gx = 2 * x0 - 3 + px;
     const bool ok = f < SNP && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((long long)cy * p.W + cx) * 4);
+    f32x4 v;
+    if (p.rgb) {  // (workgroup-uniform) three planes, one value each; consecutive lanes read consecutive pixels of a row
+      const long long o = plane0 + (long long)cy * p.W + cx;
+      float c0, c1, c2;
+      if (p.rgb_u8) {
+        const unsigned char* sp = static_cast<const unsigned char*>(p.rgb) + o;
+        c0 = (float)sp[0]; c1 = (float)sp[hw]; c2 = (float)sp[2 * hw];
+      } else {
+        const float* sp = static_cast<const float*>(p.rgb) + o;
+        c0 = sp[0]; c1 = sp[hw]; c2 = sp[2 * hw];
+      }
+      v = (f32x4){2.0f * (c0 / 255.0f) - 1.0f, 2.0f * (c1 / 255.0f) - 1.0f, 2.0f * (c2 / 255.0f) - 1.0f, 0.0f};
+    } else {
+      v = *reinterpret_cast<const f32x4*>(in + ((long long)cy * p.W + cx) * 4);
+    }
     rp[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   u32x4 rw[NWF];
@@ -758,13 +785,27 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
   return mvt_launch_status();
 }
 
-// 7x7 stride-2 pad-3 stem with Cin padded to 4 and Cout <= 64 (bf16 mode)
+// 7x7 stride-2 pad-3 stem with Cin padded to 4 and Cout <= 64 (bf16 mode); the input is either the normalised [n][H][W][4] fp32
+// tensor `in`, or (in == null) the planar clip `rgb` (V,T,3,H,W), fp32 or uint8, images rgb_img0 .. rgb_img0 + n - 1 frame-major
+__attribute__((visibility("hidden"))) int mvt_detail_stem7x7_rows_src(const float* in, const void* rgb, int rgb_u8, int rgb_V, int rgb_T,
+                                                                      long long rgb_img0, const unsigned short* w, int ldw,
+                                                                      const float* bias, void* out, int n, int H, int W, int Cout, int ldo,
+                                                                      int io_flags, float* out_partial, hipStream_t stream);
 __attribute__((visibility("hidden"))) int mvt_detail_stem7x7_rows(const float* in, const unsigned short* w, int ldw, const float* bias,
                                                                   void* out, int n, int H, int W, int Cout, int ldo, int io_flags,
                                                                   float* out_partial, hipStream_t stream) {
+  return mvt_detail_stem7x7_rows_src(in, nullptr, 0, 0, 0, 0, w, ldw, bias, out, n, H, W, Cout, ldo, io_flags, out_partial, stream);
+}
+__attribute__((visibility("hidden"))) int mvt_detail_stem7x7_rows_src(const float* in, const void* rgb, int rgb_u8, int rgb_V, int rgb_T,
+                                                                      long long rgb_img0, const unsigned short* w, int ldw,
+                                                                      const float* bias, void* out, int n, int H, int W, int Cout, int ldo,
+                                                                      int io_flags, float* out_partial, hipStream_t stream) {
   MVT_REQUIRE(Cout > 0 && Cout <= 64 && ldw >= SKW && (long long)H * W * 4 < (1LL << 31) && !(io_flags & MVT_IO_IN_BF16));
+  MVT_REQUIRE((in != nullptr) != (rgb != nullptr));
+  MVT_REQUIRE(!rgb || (rgb_V > 0 && rgb_T > 0 && rgb_img0 >= 0 && rgb_img0 + n <= (long long)rgb_V * rgb_T && (rgb_u8 == 0 || rgb_u8 == 1)));
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   RowsArgs a{};
+  a.rgb = rgb; a.rgb_u8 = rgb_u8; a.rgb_V = rgb_V; a.rgb_T = rgb_T; a.rgb_img0 = rgb_img0;
   a.in = in; a.w = w; a.bias = bias; a.out = (float*)out; a.in_stats = nullptr; a.out_part = out_partial;
   a.H = H; a.W = W; a.Cin = 4; a.Cout = Cout; a.ldw = ldw; a.ldo = ldo;
   a.slots = mvt_detail_conv_rows_slots(Ho, Wo, TR);

@@ -57,9 +57,16 @@ extern "C" long long mvt_encoder_workspace_bytes(int n, int H, int W, int C) {
     if (rc_ != MVT_OK) return rc_; \
   } while (0)
 
-extern "C" int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4, int n, int H, int W, void* out_rows, int ldo,
-                                   int out_bf16, void* workspace, long long workspace_bytes, void* stream) {
-  MVT_REQUIRE(w && x4 && out_rows && workspace && n > 0 && H >= 16 && W >= 16 && H % 4 == 0 && W % 4 == 0);
+int mvt_detail_conv_rows_slots(int Ho, int Wo, int tile_rows);
+int mvt_detail_conv_rows_tile_rows(int ksize, int stride, int Ho);
+int mvt_detail_stem7x7_rows_src(const float* in, const void* rgb, int rgb_u8, int rgb_V, int rgb_T, long long rgb_img0, const unsigned short* w,
+                                int ldw, const float* bias, void* out, int n, int H, int W, int Cout, int ldo, int io_flags, float* out_partial,
+                                hipStream_t stream);
+
+// x4 != null: normalised [n][H][W][4] input; else the planar clip rgb (V,T,3,H,W), images img0 .. img0 + n - 1 frame-major
+static int encoder_run(const mvt_encoder_weights* w, const float* x4, const void* rgb, int rgb_u8, int rgb_V, int rgb_T, long long img0,
+                       int n, int H, int W, void* out_rows, int ldo, int out_bf16, void* workspace, long long workspace_bytes, void* stream) {
+  MVT_REQUIRE(w && (x4 || rgb) && out_rows && workspace && n > 0 && H >= 16 && W >= 16 && H % 4 == 0 && W % 4 == 0);
   const int C = w->latent_dim;
   MVT_REQUIRE(C > 0 && C % 32 == 0 && ldo >= C && (out_bf16 == 0 || out_bf16 == 1));
   const Plan P = plan(n, H, W, C);
@@ -97,7 +104,18 @@ extern "C" int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4
   // stem: 7x7 / 2, its InstanceNorm + ReLU is applied by its two consumers (conv1 of layer1.0 and that block's skip)
   const int h2 = H / 2, w2 = W / 2;
   float* st_stem = nullptr;
-  ENC_TRY(conv(0, x4, 0, base + P.stem, H, W, 4, 64, 7, 2, 3, 64, nullptr, &st_stem, MVT_IO_OUT_BF16));
+  if (x4) {
+    ENC_TRY(conv(0, x4, 0, base + P.stem, H, W, 4, 64, 7, 2, 3, 64, nullptr, &st_stem, MVT_IO_OUT_BF16));
+  } else {
+    // the stem reads the clip's planar frames itself (normalisation on load): no [n][H][W][4] staging tensor, one launch less
+    const mvt_conv_weights& cw = w->conv[0];
+    const int slots = mvt_detail_conv_rows_slots(h2, w2, mvt_detail_conv_rows_tile_rows(7, 2, h2));
+    // (weight rows as mvt_conv2d_bf16 takes them: [64][round_up(7 * 32, 64)])
+    ENC_TRY(mvt_detail_stem7x7_rows_src(nullptr, rgb, rgb_u8, rgb_V, rgb_T, img0, cw.w, (7 * 32 + 63) & ~63, cw.b, base + P.stem, n, H, W, 64, 64,
+                                        MVT_IO_OUT_BF16, part, mvt_stream(stream)));
+    st_stem = new_st();
+    ENC_TRY(mvt_instnorm_finish_slots(part, slots, st_stem, n, (long long)h2 * w2, 64, stream));
+  }
 
   // ResidualBlock (blocks.py:84-128): conv1 -> IN -> ReLU -> conv2 -> IN -> ReLU, + (downsampled, normalised) input, ReLU
   auto res_block = [&](int c1, int c2, int cd, const void* xin, const float* x_stats, int hh, int ww, int cin, int cout, int stride,
@@ -141,4 +159,17 @@ extern "C" int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4
   ENC_TRY(conv(21, base + P.cat, MVT_IO_IN_BF16, base + P.c2, hs, ws, 416, 2 * C, 3, 1, 1, 2 * C, nullptr, &st_c2, MVT_IO_OUT_BF16));
   ENC_TRY(conv(22, base + P.c2, MVT_IO_IN_BF16, out_rows, hs, ws, 2 * C, C, 1, 1, 0, ldo, st_c2, nullptr, out_bf16 ? MVT_IO_OUT_BF16 : 0));
   return MVT_OK;
+}
+
+extern "C" int mvt_encoder_forward(const mvt_encoder_weights* w, const float* x4, int n, int H, int W, void* out_rows, int ldo,
+                                   int out_bf16, void* workspace, long long workspace_bytes, void* stream) {
+  MVT_REQUIRE(x4);
+  return encoder_run(w, x4, nullptr, 0, 0, 0, 0, n, H, W, out_rows, ldo, out_bf16, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvt_encoder_forward_rgb(const mvt_encoder_weights* w, const void* rgbs, int is_u8, int V, int T, long long img0, int n, int H,
+                                       int W, void* out_rows, int ldo, int out_bf16, void* workspace, long long workspace_bytes,
+                                       void* stream) {
+  MVT_REQUIRE(rgbs && (is_u8 == 0 || is_u8 == 1) && V > 0 && T > 0 && img0 >= 0 && n > 0 && img0 + n <= (long long)V * T);
+  return encoder_run(w, nullptr, rgbs, is_u8, V, T, img0, n, H, W, out_rows, ldo, out_bf16, workspace, workspace_bytes, stream);
 }

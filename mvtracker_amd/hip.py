@@ -82,6 +82,7 @@ SIGNATURES = {
     "mvt_track_metrics": [P, P, P, P, P, I, I, I, P, I, F, P, I, P],
     "mvt_encoder_workspace_bytes": [I, I, I, I],
     "mvt_encoder_forward": [P, P, I, I, I, P, I, I, P, LL, P],
+    "mvt_encoder_forward_rgb": [P, P, I, I, I, LL, I, I, I, P, I, I, P, LL, P],
     "mvt_updateformer_workspace_bytes": [I, I],
     "mvt_updateformer_forward": [P, P, I, I, P, I, P, P, P, P, LL, P],
     "mvt_updateformer_forward_tokens": [P, P, I, P, I, P, P, P, P, LL, P],
@@ -613,6 +614,13 @@ class EncoderWeights(C.Structure):
 
 def encoder_workspace_bytes(n, H, W, Cc) -> int:
     return int(_lib.mvt_encoder_workspace_bytes(n, H, W, Cc))
+
+
+def encoder_forward_rgb(weights: EncoderWeights, rgbs, V, T, img0, n, H, W, out_rows, ldo, workspace):
+    """``encoder_forward`` reading images img0 .. img0+n-1 (frame-major) of the planar clip rgbs (V,T,3,H,W) fp32 / uint8 directly."""
+    assert rgbs.is_contiguous() and rgbs.dtype in (torch.uint8, torch.float32) and tuple(rgbs.shape) == (V, T, 3, H, W)
+    _call("mvt_encoder_forward_rgb", C.addressof(weights), _ptr(rgbs), 1 if rgbs.dtype == torch.uint8 else 0, V, T, img0, n, H, W,
+          _ptr(out_rows), ldo, 1 if out_rows.dtype == torch.bfloat16 else 0, _ptr(workspace), workspace.numel(), _stream())
 
 
 def encoder_forward(weights: EncoderWeights, x4, n, H, W, out_rows, ldo, workspace):

@@ -59,6 +59,13 @@ class _Shifted:
         return self.base[sl.start - self.shift:sl.stop - self.shift]
 
 
+class _ClipImages:
+    """Images img0 .. (frame-major numbering t * V + v) of the planar clip rgbs (V,T,3,H,W), fp32 or uint8 in [0, 255], by reference."""
+
+    def __init__(self, rgbs, V, T, img0):
+        self.rgbs, self.V, self.T, self.img0 = rgbs, V, T, img0
+
+
 class MVTracker(nn.Module):
     def __init__(
             self,
@@ -139,6 +146,7 @@ class MVTracker(nn.Module):
         self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
         self.encoder_streams = int(os.environ.get("MVT_ENC_STREAMS", "2"))  # 2: the chunks of an encoder call alternate between two streams
         self.presearch = os.environ.get("MVT_PRESEARCH", "1") != "0"  # first searches of new tracks beside the first encoder block
+        self.stem_reads_clip = os.environ.get("MVT_STEM_RGB", "1") != "0"  # composite encoder: the stem reads the planar clip itself
         self.defer_encoder = os.environ.get("MVT_ENC_DEFER", "0") != "0"  # one block of later frames per window on the side stream (A/B: no gain at C3)
         self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
         self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
@@ -465,9 +473,18 @@ class MVTracker(nn.Module):
         return y2, Ho, Wo
 
     def _encode(self, pk, x4, n, H, W, out_rows):
-        """x4 (n,H,W,4) normalised RGB -> writes (n, H/4, W/4, C) into ``out_rows``."""
+        """x4 (n,H,W,4) normalised RGB -- or a ``_ClipImages`` reference to n images of the planar clip, which the composite
+        encoder's stem reads directly -- -> writes (n, H/4, W/4, C) into ``out_rows``."""
         C = self.latent_dim
-        if "encoder_struct" in pk and out_rows.is_contiguous():  # the whole CNN as ONE library call (mvt_encoder_forward)
+        composite = "encoder_struct" in pk and out_rows.is_contiguous()
+        if isinstance(x4, _ClipImages):
+            src = x4
+            if composite and self.stem_reads_clip:  # mvt_encoder_forward_rgb: no (n,H,W,4) staging tensor, one launch less
+                ws = self._workspace(hip.encoder_workspace_bytes(n, H, W, C), src.rgbs.device)
+                return hip.encoder_forward_rgb(pk["encoder_struct"], src.rgbs, src.V, src.T, src.img0, n, H, W, out_rows, C, ws)
+            x4 = torch.empty(n, H, W, 4, device=src.rgbs.device)
+            hip.rgb_images_to_nhwc4(src.rgbs, x4, src.V, src.T, H, W, src.img0, n)
+        if composite:  # the whole CNN as ONE library call (mvt_encoder_forward)
             ws = self._workspace(hip.encoder_workspace_bytes(n, H, W, C), x4.device)
             return hip.encoder_forward(pk["encoder_struct"], x4, n, H, W, out_rows, C, ws)
         hs, ws = H // self.stride, W // self.stride
@@ -515,14 +532,12 @@ class MVTracker(nn.Module):
             on_helper = two and ci % 2 == 1
             ctx = torch.cuda.stream(helper) if on_helper else contextlib.nullcontext()
             with ctx:
-                x4 = torch.empty(n, H, W, 4, device=dev)
-                hip.rgb_images_to_nhwc4(rgbs, x4, V, T, H, W, a, n)
-                self._encode(pk, x4, n, H, W, out[a:a + n])
+                # (images a .. a+n-1 of the clip by reference: the composite encoder's stem reads the planar frames itself)
+                self._encode(pk, _ClipImages(rgbs, V, T, a), n, H, W, out[a:a + n])
                 if on_helper:
                     ev = torch.cuda.Event()
                     ev.record(helper)
                     joins.append(ev)
-                    x4.record_stream(helper)
             if after_first_chunk is not None:  # (host-side hook: the GPU has work queued now, see MVTracker.forward)
                 after_first_chunk()
                 after_first_chunk = None

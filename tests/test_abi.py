@@ -36,4 +36,4 @@ def test_ctypes_table_matches_header():
 
 def test_introspection_without_gpu():
     from mvtracker_amd import hip
-    assert hip.abi_version() == 5 and hip.build_arch() == "gfx950"
+    assert hip.abi_version() == 6 and hip.build_arch() == "gfx950"

@@ -832,6 +832,33 @@ def test_composite_encoder_bit_identical(model, shape):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.uint8])
+def test_composite_encoder_stem_reads_clip(model, dtype):
+    """mvt_encoder_forward_rgb: the stem reads images img0 .. of the planar clip (V,T,3,H,W) itself -- fp32 or uint8 frames, the
+    normalisation of mvt_rgb_images_to_nhwc4 applied on load -- against the staged (n,H,W,4) input: identical features, bit for bit.
+    An image run that starts inside a frame (img0 = 3 with V = 2) and ends before the clip does."""
+    from mvtracker_amd import hip as H_
+    from mvtracker_amd.tracker import _ClipImages
+    V, T, H, W, img0, n = 2, 4, 96, 160, 3, 4
+    g = torch.Generator().manual_seed(5)
+    rgbs = (torch.rand(V, T, 3, H, W, generator=g) * 255)
+    rgbs = rgbs.round().to(torch.uint8) if dtype == torch.uint8 else rgbs
+    rgbs = rgbs.to(DEV).contiguous()
+    outs = []
+    with _with_precision(model, "bf16"):
+        pk = model._pack(torch.device(DEV))
+        assert "encoder_struct" in pk and model.stem_reads_clip
+        x4 = torch.empty(n, H, W, 4, device=DEV)
+        H_.rgb_images_to_nhwc4(rgbs, x4, V, T, H, W, img0, n)
+        for src in (x4, _ClipImages(rgbs, V, T, img0)):
+            o = torch.zeros(n, H // 4, W // 4, 128, device=DEV, dtype=torch.bfloat16)
+            model._encode(pk, src, n, H, W, o)
+            outs.append(o)
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("S,seed", [(8, 2), (16, 3)])
 def test_forward_other_window_lengths(S, seed):
     """sliding_window_len other than the shipped 12 (mvtracker.py:94-113 takes it as a constructor argument): the time attention
