@@ -37,3 +37,35 @@ def test_ctypes_table_matches_header():
 def test_introspection_without_gpu():
     from mvtracker_amd import hip
     assert hip.abi_version() == 6 and hip.build_arch() == "gfx950"
+
+
+def test_ctypes_structs_match_header_layout(tmp_path):
+    """Every struct hip.py mirrors with ctypes has the size and the field offsets the C compiler gives the header's struct:
+    a field appended to the header and forgotten in the binding (or reordered) shows here, not as a wrong pointer on the GPU.
+    gcc compiles a probe that includes include/mvtracker_hip.h as plain C and prints sizeof / offsetof."""
+    import shutil
+    import subprocess
+    import pytest
+    from mvtracker_amd import hip
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"mvt_block_next": hip.BlockNext, "mvt_block_attn": hip.BlockAttn, "mvt_knn_level": hip.KnnLevel, "mvt_lin_frag": hip.LinFrag,
+             "mvt_lin_rows": hip.LinRows, "mvt_updater_block": hip.UpdaterBlock, "mvt_updater_weights": hip.UpdaterWeights,
+             "mvt_token_inputs": hip.TokenInputs, "mvt_conv_weights": hip.ConvWeights, "mvt_encoder_weights": hip.EncoderWeights}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mvtracker_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr  # (also: the header is valid C and its field names are the binding's)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    got = {tuple(ln.split()[:2]): int(ln.split()[2]) for ln in out if ln.strip()}
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), (cname, got[(cname, "size")], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
