@@ -31,8 +31,17 @@ from . import hip
 log = logging.getLogger(__name__)
 
 
+_param_epoch = [0]  # bumped whenever a Parameter OBJECT is (re)registered anywhere in a tracker's module tree
+
+
 class _Node(nn.Module):
     """Anonymous container used to reproduce the reference's dotted state_dict keys."""
+
+    def register_parameter(self, name, param):
+        # (assigning a new nn.Parameter, load_state_dict(assign=True), ... all end here: the cached parameter list of
+        #  MVTracker._signature must be rebuilt, or a stale packed weight set would be used silently)
+        _param_epoch[0] += 1
+        super().register_parameter(name, param)
 
 
 def _insert(root: nn.Module, dotted: str, tensor: torch.Tensor) -> None:
@@ -124,6 +133,7 @@ class MVTracker(nn.Module):
         self._packed: Optional[dict] = None
         self._packed_sig = None
         self._plist = None
+        self._plist_epoch = -1
         self._slot_cache = {}
         # arithmetic of the matrix-core kernels (convs + linears); everything else is always fp32:
         #   "fp32"   v_mfma_f32_32x32x2_f32, exact fp32 FMA chains
@@ -232,6 +242,10 @@ class MVTracker(nn.Module):
         out = np.einsum("m,d->md", pos, omega)
         return torch.from_numpy(np.concatenate([np.sin(out), np.cos(out)], axis=1)).float()[:, :D].contiguous()
 
+    def register_parameter(self, name, param):
+        _param_epoch[0] += 1
+        super().register_parameter(name, param)
+
     def init_stats(self):  # reference API (mvtracker.py:190-242); statistics are not collected here
         pass
 
@@ -247,8 +261,10 @@ class MVTracker(nn.Module):
                  self.depth, self.hidden)
         # (the Parameter objects are fixed at construction -- load_state_dict / .to() change their data in place -- so the module
         #  tree is walked once: nn.Module.parameters() costs ~0.8 ms per walk, and this runs several times per call)
-        if self._plist is None:
+        #  again only after a Parameter object has been registered somewhere: _Node.register_parameter / register_parameter below)
+        if self._plist is None or self._plist_epoch != _param_epoch[0]:
             self._plist = list(self.parameters())
+            self._plist_epoch = _param_epoch[0]
         return flags + tuple(p._version for p in self._plist) + tuple(p.data_ptr() for p in self._plist)
 
     def _pack(self, dev) -> dict:
@@ -952,30 +968,34 @@ class MVTracker(nn.Module):
                     else:
                         hip.knn_scan_levels(lv0, coords, n0, S, frame0, 1, T, K, seed_k=K)
                         hip.knn_merge_levels(lv0, n0, S, K)
-                if n0 < n and pre_idx is not None:
-                    pass  # searched ahead of time
-                elif n0 < n and self.knn_one_launch and all(b is not None for b in store["box"]):
+                # rows [n1, n) were searched ahead of time (``pre_idx``: the tracks that enter at this window, i.e. everything behind the
+                # carried ones); rows [n0, n1) still need their first, unseeded search -- empty unless the carried tracks were not seeded
+                # from the previous window (``seed_across_windows`` off)
+                n1 = n if pre_idx is None else (carry[1] if carry is not None else 0)
+                if n0 >= n1:
+                    pass
+                elif self.knn_one_launch and all(b is not None for b in store["box"]):
                     # new tracks: all four levels in ONE unseeded launch (every search starts from the farthest-corner bound of the
                     # nearest full tile) -- 262 us against four dependent coarse-to-fine launches of ~100 us each
-                    m = n - n0
-                    lv1 = [dict(lv, seed_idx=None, idx_out=idx[l_][n0:]) for l_, lv in enumerate(levels)]
-                    hip.knn_search_levels(lv1, coords[n0:], m, S, frame0, 1, T, K, seed_k=0)
-                elif n0 < n:  # new tracks: coarse to fine, level l+1's neighbours bound level l's first scan
-                    m = n - n0
+                    m = n1 - n0
+                    lv1 = [dict(lv, seed_idx=None, idx_out=idx[l_][n0:n1]) for l_, lv in enumerate(levels)]
+                    hip.knn_search_levels(lv1, coords[n0:n1], m, S, frame0, 1, T, K, seed_k=0)
+                else:  # new tracks: coarse to fine, level l+1's neighbours bound level l's first scan
+                    m = n1 - n0
                     for lvl in reversed(range(L)):
                         P = store["P"][lvl]
                         seed = {}
                         if lvl + 1 < L and grid[lvl][0] >= 2 * grid[lvl + 1][0] and grid[lvl][1] >= 2 * grid[lvl + 1][1]:
-                            seed = dict(seed_idx=idx[lvl + 1][n0:], seed_k=K,
+                            seed = dict(seed_idx=idx[lvl + 1][n0:n1], seed_k=K,
                                         seed_dims=(grid[lvl + 1][1], grid[lvl + 1][0], grid[lvl][1], grid[lvl][0]))
                         if self.knn_one_launch:
-                            hip.knn_search(store["xyz"][lvl], P, coords[n0:], m, S, frame0, 1, T, K, idx[lvl][n0:], store["box"][lvl],
+                            hip.knn_search(store["xyz"][lvl], P, coords[n0:n1], m, S, frame0, 1, T, K, idx[lvl][n0:n1], store["box"][lvl],
                                            grid=store["tile_grid"][lvl], gbox=store["gbox"][lvl], **seed)
                             continue
-                        kl = keys[lvl][n0 * S * nsegs[lvl] * K:]
-                        hip.knn_scan(store["xyz"][lvl], P, coords[n0:], m, S, frame0, 1, T, K, nsegs[lvl], kl, box=store["box"][lvl],
+                        kl = keys[lvl][n0 * S * nsegs[lvl] * K:n1 * S * nsegs[lvl] * K]
+                        hip.knn_scan(store["xyz"][lvl], P, coords[n0:n1], m, S, frame0, 1, T, K, nsegs[lvl], kl, box=store["box"][lvl],
                                      grid=store["tile_grid"][lvl], **seed)
-                        hip.knn_merge(kl, m, S, K, nsegs[lvl], P, idx[lvl][n0:])
+                        hip.knn_merge(kl, m, S, K, nsegs[lvl], P, idx[lvl][n0:n1])
             if default_corr:
                 hip.corr_gather_dot(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S, frame0,
                                     1, T, K, fcorr, Fc, 0)

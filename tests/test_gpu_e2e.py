@@ -412,6 +412,30 @@ def test_encoder_bf16_vs_reference(model, golden, W):
     _bf16_stage_check("encoder", out.float().permute(0, 3, 1, 2).cpu().numpy(), g["out"], ac, (5e-2, 4.5e-2))
 
 
+@pytest.mark.parametrize("V,H,Wd,dtype", [(2, 512, 512, np.float32), (1, 720, 1280, np.uint8)])
+def test_encoder_bf16_full_size_vs_oracle(model, W, V, H, Wd, dtype):
+    """The encoder as the BENCHMARK runs it -- the composite mvt_encoder_forward_rgb, stem reading the planar clip, conv_rows_bf16
+    tiles in their XCD-aware order, stride-2 split rows and edge tiles at the real image sizes -- against the oracle's BasicEncoder
+    (spatracker/blocks.py:214-284) on the same images: 512 x 512 fp32 frames (BASELINE config C3: 16 x 64 output tiles per image at
+    the stem's resolution) and a 720 x 1280 uint8 frame (config C5: 180 x 320 features, tile rows that do not divide the image).
+    Rule of _bf16_stage_check (test_encoder_bf16_vs_reference covers 64 x 96 against the reference's own fixture)."""
+    from mvtracker_amd.tracker import _ClipImages
+    clip = synth.make_clip(91, V=V, T=1, H=H, W=Wd, N=1, rgb_dtype=dtype)
+    rgbs = T(clip["rgbs"])[0]                                     # (V, 1, 3, H, W), integer-valued in [0, 255]
+    x = 2 * (rgbs.float().reshape(V, 3, H, Wd) / 255.0) - 1       # mvtracker.py:566
+    with torch.no_grad():
+        ref = O.encoder(W, x).numpy()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ac = O.encoder(W, x).float().numpy()
+    with _with_precision(model, "bf16"):
+        pk = model._pack(torch.device(DEV))
+        assert "encoder_struct" in pk and model.stem_reads_clip
+        out = torch.zeros(V, H // 4, Wd // 4, 128, device=DEV, dtype=model.store_dtype())
+        model._encode(pk, _ClipImages(rgbs.to(DEV).contiguous(), V, 1, 0), V, H, Wd, out)
+        torch.cuda.synchronize()
+    _bf16_stage_check(f"encoder {H}x{Wd}", out.float().permute(0, 3, 1, 2).cpu().numpy(), ref, ac, (5e-2, 4.5e-2))
+
+
 def test_updateformer_bf16_vs_reference(model, golden, W):
     """The benchmarked updater (mvt_updateformer_forward: fused block kernels, in-kernel attention, hidden 256, bf16 q/k/v) against
     the REFERENCE's fp32 EfficientUpdateFormer output (updateformer_16x12.npz); the reference under autocast: max 1.1e-2 / mean 9e-3."""
@@ -505,10 +529,31 @@ def _check_sampled_rows(model, store, frame0, coords, feats, n_sample=64, seed=0
     return max(_check_iteration_rows(model, store, frame0, tr, it, sample, fcorr_tol) for it in range(iters))
 
 
-def _check_forward_trace(model, a, n_sample=48, iters=4, fcorr_tol=5e-5):
+def _check_updater_calls(model, W, tr, picks, cap):
+    """The UPDATER as the traced forward ran it -- at the benchmark's row counts, i.e. the 64-row big-block kernels
+    (block_fused_bf16<2,0,1> with the block-diagonal time attention, <2,0,6> finishing the virtual-self block's pass 2), the
+    workgroup-split key-split attention_mfma_kernel<4> and the split path of the virtual-track blocks -- against the oracle's
+    EfficientUpdateFormer (cotracker2/blocks.py:455-494) on the device's OWN token rows of that call (teacher-forced: tokens in,
+    delta out, ``tokens`` / ``delta`` of the trace).  Rule of _bf16_stage_check: at most 10 % worse than what bf16 autocast
+    costs the reference on the same tokens, plus an absolute cap.  ``picks`` = [(window, iteration), ...]."""
+    res = []
+    for wi, it in picks:
+        tok = tr[wi]["tokens"][it].cpu().float()[None]          # (1, n, S, D)
+        got = tr[wi]["delta"][it].cpu().float().numpy()[None]   # (1, n, S, 3 + C)
+        with torch.no_grad():
+            ref = O.update_former(W, tok, CFG).numpy()
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                ac = O.update_former(W, tok, CFG).float().numpy()
+        _bf16_stage_check(f"updater call, window {wi} iteration {it}, n = {tok.shape[1]}", got, ref, ac, cap)
+        res.append(tok.shape[1])
+    return res
+
+
+def _check_forward_trace(model, a, n_sample=48, iters=4, fcorr_tol=5e-5, updater=None):
     """A whole traced forward on a prebuilt store: EVERY iteration of EVERY window -- the unseeded first search of new tracks, the
     seeded searches of iterations 1..3 and the first search of carried tracks, seeded by the previous window's neighbours through
-    the slot shift s -> s + S/2 -- teacher-forced against the oracle for sampled carried and new tracks."""
+    the slot shift s -> s + S/2 -- teacher-forced against the oracle for sampled carried and new tracks.  ``updater`` =
+    (oracle weights, [(window, iteration), ...], cap): additionally those updater calls against the oracle (_check_updater_calls)."""
     store = model.build_frame_store(a[0][0], a[1][0], a[3][0], a[4][0])
     tr = []
     model(*a, iters=iters, frame_store=store, trace=tr)
@@ -529,6 +574,8 @@ def _check_forward_trace(model, a, n_sample=48, iters=4, fcorr_tol=5e-5):
             worst = max(worst, _check_iteration_rows(model, store, w, wt, it, sample, fcorr_tol))
         p0 = p1
     assert n_carried > 0
+    if updater is not None:
+        _check_updater_calls(model, updater[0], tr, updater[1], updater[2])
     return worst
 
 
@@ -548,7 +595,7 @@ def _query_state(model, a, store, t=0):
     return xyz[:, None, :].repeat(1, model.S, 1), feat[:, None, :].repeat(1, model.S, 1).contiguous()
 
 
-def test_c3_bf16_full_size(model):
+def test_c3_bf16_full_size(model, W):
     """BASELINE config C3 in ITS dtype: 4 views x 24 frames x 512^2, 1024 queries, bf16.  Size-independent properties (finite,
     bit-deterministic, shard = independent forward, untouched frames before a late query, track at its query frame within the
     refinement deltas) plus the teacher-forced sampled-row check of kNN / correlation against the oracle on the same store."""
@@ -576,7 +623,9 @@ def test_c3_bf16_full_size(model):
         w = _check_sampled_rows(model, store, 0, coords, feats)
         print(f"C3 bf16: sampled fcorr rows max abs err {w:.2e}")
         del store
-        w = _check_forward_trace(model, a)  # 3 windows x 4 iterations, carried + new tracks, seeded searches at the C3 scale
+        # 3 windows x 4 iterations, carried + new tracks, seeded searches at the C3 scale; and the updater calls of the benchmark's
+        # shape (n ~ 1 000 tracks = 12 k point rows: the 64-row big blocks, the workgroup-split key-split attention) against the oracle
+        w = _check_forward_trace(model, a, updater=(W, [(0, 0), (0, 3), (1, 1), (2, 2)], (2.5e-2, 2e-2)))
         print(f"C3 bf16: every window / iteration teacher-forced, fcorr rows max abs err {w:.2e}")
 
 
@@ -610,7 +659,7 @@ def test_c2_full_size_fp32_invalid_depth(model, W):
         _check_forward_trace(model, a, n_sample=32)
 
 
-def test_c5_shard_720p_bf16(model):
+def test_c5_shard_720p_bf16(model, W):
     """One GPU's share of BASELINE config C5: 6 views x 64 frames x 720x1280, 512 queries, bf16, 10 sliding windows.  The feature
     pyramid is 180x320 -> 90x160 -> 45x80 -> 22x40: an odd level whose last row avgpool2 / the nearest depth subsample drop, and
     levels that are not multiples of 8 (linear kNN tiles).  uint8 frames (1 GB instead of 4 GB); 4 rendered frames per view,
@@ -633,7 +682,8 @@ def test_c5_shard_720p_bf16(model):
         # carried windows at this pyramid shape (two linear-tile levels): the first 18 frames of the same clip, two windows
         a18 = [a[0][:, :, :18].contiguous(), a[1][:, :, :18].contiguous(), a[2].clone(), a[3][:, :, :18].contiguous(), a[4][:, :, :18].contiguous()]
         a18[2][0, :, 0] = torch.where(a18[2][0, :, 0] > 7, torch.full_like(a18[2][0, :, 0], 7.0), a18[2][0, :, 0])
-        _check_forward_trace(model, a18, n_sample=32)
+        # (... and the updater at this shard's size, ~500 tracks = 6 k point rows: the form the small-M big blocks take)
+        _check_forward_trace(model, a18, n_sample=32, updater=(W, [(0, 1), (1, 2)], (2.5e-2, 2e-2)))
     torch.cuda.empty_cache()
 
 
@@ -741,7 +791,7 @@ def test_updater_fused_attention_matches_separate_launches(model, n):
         rel = ((outs[f] - outs[0]).abs().max() / outs[0].abs().max()).item()
         mean = ((outs[f] - outs[0]).abs().mean() / outs[0].abs().mean()).item()
         print(f"n={n} fuse_attention={f}: max {rel:.2e} mean {mean:.2e}")
-        assert rel < 3e-2 and mean < 1e-2, (f, rel, mean)
+        assert rel < 1.1e-2 and mean < 9e-3, (f, rel, mean)  # 1.5 x the measured 7e-3 / 6e-3
 
 
 def test_single_point_streams_match_sequential(model):
@@ -804,6 +854,33 @@ def test_in_kernel_token_assembly_bit_identical(model):
             model.fuse_tokens = old
     model.check_finite()
     assert torch.equal(t1, r2["traj_e"]) and torch.equal(v1, r2["vis_e"])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_presearch_without_window_seeding(model, prec):
+    """The searches issued ahead of time (``presearch``: the NEW tracks of every window, beside the encoder) combined with
+    ``seed_across_windows=False``: the carried tracks then need their own unseeded first search in the window -- round 3 skipped it
+    whenever a pre-searched buffer existed and correlated the carried tracks with uninitialised neighbour indices.  Every
+    combination of the two switches is an exact search: identical results, bit for bit (three windows, late queries)."""
+    clip = synth.make_clip(44, V=2, T=24, H=128, W=128, N=40, late_queries=True, query_frames=(3, 7, 13))
+    a = args_of(clip, DEV)
+    outs = {}
+    with _with_precision(model, prec):
+        old = model.presearch, model.seed_across_windows
+        try:
+            for pre in (True, False):
+                for seed in (True, False):
+                    model.presearch, model.seed_across_windows = pre, seed
+                    r = model(*a, iters=3)
+                    outs[(pre, seed)] = (r["traj_e"].clone(), r["vis_e"].clone())
+                    model.check_finite()
+            torch.cuda.synchronize()
+        finally:
+            model.presearch, model.seed_across_windows = old
+    assert len(model.last_windows) == 3
+    t0, v0 = outs[(False, False)]
+    for k, (t, v) in outs.items():
+        assert torch.equal(t, t0) and torch.equal(v, v0), k
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 96), (2, 180, 320)])
