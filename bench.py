@@ -113,6 +113,53 @@ def cpu_baseline(args, V, HW):
                       f"{dt:.1f} s wall"}
 
 
+def two_clips_in_flight(model, a, args, MVTracker, synth, dev, V, T, H, W, Nq, clip_kw, prec):
+    """Throughput with TWO independent clips in flight on one GPU: two model objects (same weights; every piece of per-call scratch
+    and every helper stream is private to its forward), two host threads, two HIP streams, two different clips.  One clip's
+    virtual-track chain (<= 96 busy CUs) runs beside the other's 12 k-row blocks.  A serving-layer figure: the reference forward is
+    batch 1 (mvtracker.py:275, 503), so this is NEVER the headline `value`."""
+    import threading
+    m2 = MVTracker(hidden_size=256).eval()
+    m2.load_state_dict(model.state_dict(), strict=True)
+    m2.to(dev)
+    m2.precision = prec
+    c2 = synth.make_clip(4321, V=V, T=T, H=H, W=W, N=Nq, **clip_kw)
+    b = {k: torch.from_numpy(v).to(dev) for k, v in c2.items()}
+    models, clips = [model, m2], [a, b]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    K = max(2, args.steps // 2)
+
+    def call(j):
+        c = clips[j]
+        return models[j](c["rgbs"], c["depths"], c["query_points"], c["intrs"], c["extrs"], iters=args.iters)
+
+    ref = [call(j)["traj_e"].clone() for j in range(2)]  # one clip at a time (also warms the second model up)
+    torch.cuda.synchronize()
+    outs = [None, None]
+
+    def worker(j):
+        with torch.cuda.stream(streams[j]):
+            for _ in range(K):
+                outs[j] = call(j)["traj_e"]
+
+    ms = None
+    for _ in range(2):  # warm-up round, then the timed one
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(j,)) for j in range(2)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / (2 * K) * 1e3
+    same = all(torch.equal(outs[j], ref[j]) for j in range(2))
+    return {"value": Nq * T / (ms * 1e-3), "unit": "query-points*frames/s", "ms_per_clip": ms, "clips_in_flight": 2, "clips_timed": 2 * K,
+            "results_identical_to_one_at_a_time": bool(same),
+            "note": "two independent clips in flight on ONE GPU (two model objects / host threads / streams); a serving-layer throughput, "
+                    "not the headline value: the reference forward is batch 1"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +176,13 @@ def main():
                     help="matrix-core arithmetic of convs/linears (default: the config's dtype; BASELINE.json quotes C3 in bf16)")
     ap.add_argument("--cpu-hw", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-corr-calibration", action="store_true",
+                    help="skip the back-to-back calibration launches of the correlation kernel after the timed region (use under rocprofv3: "
+                         "the roofline kernel's row of the kernel statistics then holds the in-situ launches only)")
+    ap.add_argument("--clips-in-flight", type=int, default=1, choices=[1, 2],
+                    help="2: AFTER the headline measurement, additionally time two independent clips in flight (two model objects, two "
+                         "host threads, two streams) and print it as the separate field `throughput_two_clips` (never `value`: the "
+                         "reference forward is batch 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,16 +269,18 @@ def main():
     model.check_finite()
     # Calibration of the HIP-event timing of the correlation kernel, outside the timed region, with the operands of the last launch
     # and nothing else on the chip: (a) the same launch 20 x back to back inside ONE event pair -> its duration alone, launch gaps
-    # included, no event cost; (b) 20 single launches, one event pair each, exactly as they are timed in situ.  (b) - (a) is what an
-    # event pair adds to a ~35 us kernel (the marker packets' own latency) and is subtracted from the in-situ average below; the
-    # raw figures stay in the JSON line (frac_raw, avg_launch_ms_raw).
-    alone_b2b_ms = ev_overhead_ms = None
-    if rank == 0 and "corr" in last_call:
+    # included, no event cost (the ~225 MB it touches may stay cache-resident between the repeats: a WARM figure); (b) 20 single
+    # launches, one event pair each, exactly as they are timed in situ: (b) - (a) is what an event pair adds to a ~35 us kernel (the
+    # marker packets' own latency); (c) single launches, each behind a 512 MiB write to another buffer (nothing of the store is left
+    # in the 256 MiB Infinity Cache): the COLD figure alone on the chip.  `roofline.frac` is the in-situ measurement as it is; the
+    # corrected and the alone figures are reported under their own keys.  --no-corr-calibration skips all of this (rocprofv3 runs).
+    alone_b2b_ms = ev_overhead_ms = alone_cold_ms = None
+    if rank == 0 and "corr" in last_call and not args.no_corr_calibration:
         cargs, ckw = last_call["corr"]
         torch.cuda.synchronize()
         for _ in range(5):
             real_corr(*cargs, **ckw)
-        b2b, single = [], []
+        b2b, single, cold = [], [], []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -242,8 +298,24 @@ def main():
                 pairs.append((e0, e1))
             torch.cuda.synchronize()
             single += [e0.elapsed_time(e1) for e0, e1 in pairs]
+        flush = torch.empty(512 << 20, device=dev, dtype=torch.uint8)
+        pairs = []
+        for _ in range(12):
+            flush.fill_(1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            real_corr(*cargs, **ckw)
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        cold = [e0.elapsed_time(e1) for e0, e1 in pairs[2:]]
+        del flush
         alone_b2b_ms = float(np.median(b2b))
         ev_overhead_ms = max(0.0, float(np.median(single)) - alone_b2b_ms)
+        alone_cold_ms = float(np.median(cold)) - ev_overhead_ms
+    two_clips = None
+    if rank == 0 and world == 1 and args.clips_in_flight == 2:
+        two_clips = two_clips_in_flight(model, a, args, MVTracker, synth, dev, V, T, H, W, Nq, clip_kw, prec)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -258,9 +330,9 @@ def main():
         full = [(e0.elapsed_time(e1), rows) for e0, e1, rows in corr_ev if rows == Nq * model.S]
         raw_ms = float(np.mean([m for m, _ in full])) if full else float("nan")
         ev_overhead_ms = ev_overhead_ms or 0.0
-        kern_ms = raw_ms - ev_overhead_ms  # launch duration without the event pair's own cost
+        kern_ms = raw_ms - ev_overhead_ms  # launch duration without the event pair's own cost (a derived figure: own key)
         alg = model.corr_n_levels * corr_algorithmic_bytes(Nq * model.S, model.corr_neighbors, model.latent_dim, 2 if store_bf16 else 4)
-        achieved = alg / (kern_ms * 1e-3) / 1e9 if full else float("nan")
+        achieved = alg / (raw_ms * 1e-3) / 1e9 if full else float("nan")  # as measured in situ, nothing subtracted
         # the launches of the LAST window run alone on the chip; the earlier windows share HBM with the encoder of the later frames
         # on the second stream.  per step: windows x iters full launches, in order
         per_win = args.iters
@@ -271,7 +343,7 @@ def main():
         # HBM traffic of the roofline kernel: an OFFLINE PMC measurement committed under profiles/ (tools/pmc_traffic.sh: counters
         # cannot be collected from inside the timed run).  Only quoted for the workload it was measured on; the source is named.
         traffic, traffic_source = None, None
-        for name in ("r03_corr_traffic.json", "r02_corr_traffic.json", "r01_corr_traffic.json"):
+        for name in ("r04_corr_traffic.json", "r03_corr_traffic.json", "r02_corr_traffic.json", "r01_corr_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -324,22 +396,26 @@ def main():
                        "frame_store": "bf16 rows" if store_bf16 else "fp32 rows"},
             "roofline": {"bound": "hbm", "kernel": "corr_gather_dot_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         # `achieved` prices the ALGORITHMIC bytes over the average in-situ launch duration
-                         # (all windows: two of three share HBM with the encoder stream), the measured event-pair overhead
-                         # subtracted; `frac_alone`: the same launch alone on the chip, 20 x back to back in one event pair (no
-                         # event cost at all); `frac_last_window`: the in-situ launches of the last window (no encoder stream);
-                         # `frac_raw`: in situ, nothing subtracted
-                         "frac_alone": (alg / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
+                         # `achieved` / `frac` price the ALGORITHMIC bytes over the average in-situ launch duration
+                         # as the HIP events measured it (all windows: two of three share HBM with the encoder stream; the event
+                         # pair's own cost included).  Derived figures, each under its own key: `frac_event_corrected`: the measured
+                         # event-pair overhead subtracted; `frac_alone_cold`: one launch alone on the chip behind a 512 MiB cache
+                         # flush; `frac_alone_warm`: 20 x back to back in one event pair (operands may stay cache-resident);
+                         # `frac_last_window`: the in-situ launches of the last window (no encoder stream), overhead subtracted
+                         "frac_event_corrected": (alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (full and ev_overhead_ms) else None,
+                         "frac_alone_cold": (alg / (alone_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (alone_ms and alone_cold_ms) else None,
+                         "frac_alone_warm": (alg / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_ms else None,
                          "frac_last_window": (alg / (last_win_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if last_win_ms else None,
-                         "frac_raw": (alg / (raw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if full else None,
-                         "hbm_GBps_from_traffic": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and full) else None,
+                         "hbm_GBps_from_traffic": (traffic / (raw_ms * 1e-3) / 1e9) if (traffic and full) else None,
                          "algorithmic_bytes_per_launch": alg, "bytes_per_unit": alg // (model.corr_n_levels * Nq * model.S),
-                         "avg_launch_ms": kern_ms, "avg_launch_ms_raw": raw_ms, "event_pair_overhead_ms": ev_overhead_ms,
-                         "avg_launch_ms_alone": alone_ms, "launches_timed": len(full),
-                         "min_launch_ms": (float(np.min([m for m, _ in full])) - ev_overhead_ms) if full else None},
+                         "avg_launch_ms": raw_ms, "avg_launch_ms_event_corrected": kern_ms, "event_pair_overhead_ms": ev_overhead_ms,
+                         "avg_launch_ms_alone_warm": alone_ms, "avg_launch_ms_alone_cold": alone_cold_ms if alone_ms else None,
+                         "launches_timed": len(full), "min_launch_ms": float(np.min([m for m, _ in full])) if full else None},
             "roofline_mfma": {"updater": mfma(upd_fl, upd_ms, len(upd_ev) // args.steps, upd_sum),
                               "encoder": mfma(enc_fl, enc_ms, len(enc_ev) // args.steps, enc_sum)},
         }
+        if two_clips is not None:
+            out["throughput_two_clips"] = two_clips
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, V, (H, W))
         print(json.dumps(out), flush=True)

@@ -73,10 +73,10 @@ template <int TN> constexpr int stage_elems() { return 32 * (TN * 32 + 8); }
 // Statistics: every (tile row, channel) leaves its (sum, sum of squares) over the row's 32 pixels in the workgroup's LDS table
 // wst[tile row][BN][2] (pre-zeroed; lrow0 = first tile row of this wave); the kernel adds the rows up in a fixed order and writes
 // ONE slot per workgroup (tile) -- eight times fewer partials to write and to reduce than one slot per row segment.
-template <int TM, int TN, bool QUADS, bool STAGED>
+template <int TM, int TN, bool QUADS, bool STAGED, int WLD = TN * 32>
 __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const RowsArgs& p, long long img, int Ho, int Wo, int yw, int x0,
                                               int n0, int tiles_x, int tx, int lane, unsigned short* stage, float* wst, int lrow0) {
-  constexpr int BNS = TN * 32;
+  constexpr int BNS = WLD;  // channels per row of the statistics table (the workgroup's channel count)
   const int r = lane & 31, h = lane >> 5;
 #ifndef MVT_EPI_NO_TR
   if constexpr (STAGED && TN * 32 * 36 <= stage_elems<TN>()) {  // (96-channel tiles: the transposed tile does not fit their staging area)
@@ -703,6 +703,199 @@ __global__ __launch_bounds__(256) void stem7x7_rows_bf16(RowsArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the wide 3x3 / stride-1 convolution (BasicEncoder.conv2, 416 -> 256 channels at H/4: 45 % of the encoder's flops,
+// spatracker/blocks.py:246-282) as ONE 512-thread workgroup per CU that owns an 8 x 32 pixel tile and ALL 256 output channels
+// of a channel block.  In-kernel stamps of the row-tile kernel on this layer (gpurun_out/r4_stamp_c2.txt): of a 32-channel
+// chunk's 13.5 k cycles only the three MFMA segments (7 k) compute -- the rest is the register-staged loader (patch 2-3 k) and two
+// barriers per 24 MFMAs (3 k) -- and inside the segments every group of MFMAs waits for the LDS reads issued just ahead of it (no
+// registers left to read further ahead at 168 VGPRs / three workgroups per CU).  Here:
+//   * patch and weights travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write, no VALU),
+//     double-buffered, requested one stage (= one filter row of a 32-channel chunk: 48 MFMAs per wave) ahead; ONE raw barrier per
+//     stage, every wave waits for its own DMAs (vmcnt(0)) just before it -- the stage's MFMAs cover their latency;
+//   * the LDS images are unpadded 64-B slots (a 1-KiB DMA instruction is 16 whole slots, 4 lanes = one slot = one 64-B global
+//     segment: coalesced) with the 16-B pieces of a slot XOR-swizzled by the slot's patch column / weight row (>> 2) & 3 -- applied
+//     on the SOURCE address of the DMA and on the read address (cdna_hip_programming.md rule 21): conflict-free ds_read_b128;
+//   * wave tile 4 rows x 64 channels (8 accumulators, 0.75 KiB of LDS reads per MFMA), the next group's six fragments are read
+//     while the current group's eight MFMAs issue (two fragment sets, 256-VGPR budget at two waves per SIMD);
+//   * the input patch is fetched ONCE per pixel tile (the 64-channel tiles re-read it four times through L2).
+// Same accumulation order per accumulator (chunk, kh, kw, k-step) and the same epilogue as conv_rows_bf16: bit-identical outputs
+// and statistics (tests/test_gpu_ops.py::test_conv_big_tile_bit_identical).
+constexpr int BG_BN = 256;                               // output channels per workgroup
+constexpr int BG_PC = TC + 2;                            // 34 patch columns (10 patch rows)
+constexpr int BG_PSLOTS = (TR + 2) * BG_PC;              // 340 pixel slots of 64 B
+constexpr int BG_PINSTR = 24;                            // DMA wave-instructions per patch chunk: 3 per wave (21.25 carry pixels)
+constexpr int BG_PBYTES = BG_PINSTR * 1024;              // 24 576 B per patch buffer
+constexpr int BG_PROW = BG_PC * 64;                      // 2 176 B per patch row
+constexpr int BG_WBYTES = 3 * BG_BN * 64;                // 49 152 B per weight stage (3 taps x 256 rows x 32 channels)
+constexpr int BG_WST = TR * BG_BN * 2 * 4;               // 16 384 B: per (tile row, channel) output statistics (reuse the weight buffers)
+constexpr int BG_LDS = 2 * BG_PBYTES + 2 * BG_WBYTES;    // 147 456 B of the 163 840 a workgroup may own
+static_assert(BG_PSLOTS * 64 <= BG_PBYTES, "patch slots fit the buffer");
+static_assert(BG_WBYTES / 1024 == 6 * 8, "six weight DMA wave-instructions per wave and stage");
+static_assert(BG_LDS <= 160 * 1024 && BG_WST <= 2 * BG_WBYTES, "one workgroup per CU");
+static_assert(8 * stage_elems<2>() * 2 <= 2 * BG_PBYTES, "the epilogue's staging tiles reuse the patch buffers");
+
+__device__ __attribute__((aligned(64))) unsigned mvt_conv_zero_page[16];  // source of the DMA lanes that fall outside the image
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+__device__ __forceinline__ void dma16(const void* src, unsigned char* lds_dst_uniform) {
+  // 64 lanes x 16 B: lane l's bytes land at lds_dst_uniform + 16 l (the destination is a wave-uniform base in M0, the source per
+  // lane).  Inline asm, M0 saved / restored around it (cdna_hip_programming.md section 5.7): issued through
+  // __builtin_amdgcn_global_load_lds the waitcnt pass treats every later ds_read as unordered against it and waits lgkmcnt(0)
+  // where a counted wait would do (the fragment reads of the NEXT group were drained before every group's MFMAs).  The pass does
+  // not see these requests at all: the kernel waits for them itself (s_waitcnt vmcnt(0) ahead of each stage's barrier).
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_ptr)lds_dst_uniform);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(dst)
+               : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_big_bf16(RowsArgs p) {
+  constexpr int TM = 4, TN = 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[BG_LDS];  // (ONE LDS object: patch x2 | weights x2)
+  unsigned char* const Pb = lds;
+  unsigned char* const Wb = lds + 2 * BG_PBYTES;
+  float* const wst = reinterpret_cast<float*>(Wb);  // after the loop: the statistics table reuses the weight buffers
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave & 1, wn = wave >> 1;   // rows 4 wm .. 4 wm + 3 of the tile, channels 64 wn .. 64 wn + 63 of the block
+  const int r = lane & 31, h = lane >> 5;
+  const int Ho = p.H, Wo = p.W;
+  const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + TR - 1) / TR;
+  const int tiles_n = p.Cout / BG_BN;
+  int b;
+  {  // XCD-aware tile order, as in conv_rows_bf16: every XCD owns a contiguous run of tiles (neighbours share halo rows in its L2)
+    const unsigned nwg = gridDim.x, q = nwg / 8, rr = nwg % 8, xcd = blockIdx.x % 8;
+    b = (int)((xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + blockIdx.x / 8);
+  }
+  const int tn = b % tiles_n; b /= tiles_n;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const long long img = b / tiles_y;
+  const int y0 = ty * TR, x0 = tx * TC, n0 = tn * BG_BN;
+  const unsigned char* const in_img = reinterpret_cast<const unsigned char*>(p.in) + img * (long long)p.H * p.W * p.Cin * 2;
+  const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(p.w);
+  const unsigned char* const zero = reinterpret_cast<const unsigned char*>(mvt_conv_zero_page);
+
+  // ---- DMA lane state.  Patch: instruction k = wave + 8 i (i < 3) fills LDS pieces 64 k .. 64 k + 63 of a patch buffer; piece P
+  // = slot P >> 2 (patch row py, column px), stored piece P & 3 holds channel piece (P & 3) ^ ((px >> 2) & 3) of the chunk.
+  // (every wave issues all three instructions -- the stage loop stays free of branches, which cost the waitcnt pass its exact
+  //  LDS counts; pieces behind the last slot and pixels outside the image read the zero page)
+  int poff[3];  // byte offset inside the image (without the chunk offset), or -1: outside the image / behind the last slot
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int P = (wave + 8 * i) * 64 + lane;
+    const int slot = P >> 2, py = slot / BG_PC, px = slot - py * BG_PC;
+    const int q = (P & 3) ^ ((px >> 2) & 3);
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool ok = slot < BG_PSLOTS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    poff[i] = ok ? ((gy * p.W + gx) * p.Cin + q * 8) * 2 : -1;
+  }
+  // Weights: instruction k = wave + 8 i (i < 6) fills rows 16 k .. 16 k + 15 of a stage buffer; row R = tap kw = R >> 8 of the
+  // stage's filter row, output channel n0 + (R & 255); stored piece (lane & 3) holds channel piece (lane & 3) ^ ((R >> 2) & 3)
+  int woff[6];  // byte offset inside the weight matrix (without the stage's (kh, chunk) offset)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int R = (wave + 8 * i) * 16 + (lane >> 2);
+    const int q = (lane & 3) ^ ((R >> 2) & 3);
+    woff[i] = ((n0 + (R & 255)) * p.ldw + (R >> 8) * p.Cin + q * 8) * 2;
+  }
+  // (one instruction at a time: inside the stage loop the requests are spread over the MFMA groups; `dst_stage` / `dst_c` pick the
+  //  buffer, so that behind the last stage / chunk a harmless re-read of the current one goes to the idle buffer: no branches)
+  auto dma_weight = [&](int stage, int dst_stage, int i) {  // stage = 3 chunk + kh; i < 6
+    const int c = stage / 3, kh = stage - 3 * c;
+    dma16(wbase + ((long long)kh * 3 * p.Cin + c * CK) * 2 + woff[i], Wb + (dst_stage & 1) * BG_WBYTES + wave * 1024 + i * 8192);
+  };
+  auto dma_patch1 = [&](int c, int dst_c, int i) {  // i < 3
+    dma16(poff[i] >= 0 ? in_img + c * CK * 2 + poff[i] : zero, Pb + (dst_c & 1) * BG_PBYTES + wave * 1024 + i * 8192);
+  };
+
+  const int nchunk = p.Cin / CK;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dma_patch1(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dma_weight(0, 0, i);
+
+  // ---- fragment read bases.  A: lane (r, h) of tap kw, k-step ks reads slot (row, kw + r), piece (2 ks + h) ^ (((kw + r) >> 2) & 3);
+  // B: row kw * 256 + 64 wn + 32 j + r, piece (2 ks + h) ^ ((r >> 2) & 3).  Rows / taps / channel blocks are immediate offsets.
+  int pa[3][2], wl[2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      pa[kw][ks] = (TM * wm * BG_PC + kw + r) * 64 + (((2 * ks + h) ^ (((kw + r) >> 2) & 3)) << 4);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) wl[ks] = (64 * wn + r) * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  for (int c = 0; c < nchunk; ++c) {
+    const unsigned char* const Pc = Pb + (c & 1) * BG_PBYTES;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int stage = 3 * c + kh;
+      // every wave's DMAs of this stage have landed (its own vmcnt(0), then the barrier), and every wave is done reading the
+      // buffers the next stage's DMAs overwrite (its MFMAs consumed those reads before it got here)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int stage_n = stage + 1 < 3 * nchunk ? stage + 1 : stage, chunk_n = c + 1 < nchunk ? c + 1 : c;  // sources of the requests
+      const unsigned char* const Wc = Wb + (stage & 1) * BG_WBYTES;
+      bf16x8 a[2][TM], bb[2][TN];
+      auto read_group = [&](int set, int g) {
+        const int kw = g >> 1, ks = g & 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pc + pa[kw][ks] + (i + kh) * BG_PROW));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wc + wl[ks] + kw * (BG_BN * 64) + j * 2048));
+      };
+      read_group(0, 0);
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        // the next group's fragments are requested before this group's MFMAs issue (pinned: left free, the scheduler sinks every
+        // read to just ahead of its first use and each group of four MFMAs waits out an LDS round trip); the stage's DMA
+        // requests are spread over the groups: weights of the next stage behind groups 0-2, the next chunk's patch behind 3-5
+        if (g + 1 < 6) read_group((g + 1) & 1, g + 1);
+        if (g < 3) {
+          dma_weight(stage_n, stage + 1, 2 * g);
+          dma_weight(stage_n, stage + 1, 2 * g + 1);
+        }
+        if (g >= 3 && kh == 0) dma_patch1(chunk_n, c + 1, g - 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][i], bb[g & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wave is done with the patch / weight buffers: the staging tiles reuse the patch buffers
+  // this wave's part of the statistics table (its rows x its channels; rows past the image stay zero) -- written below by the same wave
+  for (int i = lane; i < TM * 64 * 2; i += 64) wst[((wm * TM + (i >> 7)) * BG_BN + wn * 64) * 2 + (i & 127)] = 0.f;
+
+  epilogue_rows<TM, TN, false, true, BG_BN>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, n0 + wn * 64, tiles_x, tx, lane,
+                                             reinterpret_cast<unsigned short*>(Pb) + wave * stage_elems<TN>(), wst + wn * 64 * 2, wm * TM);
+  if (p.out_part) {
+    __syncthreads();
+    write_tile_stats<TR, BG_BN>(p, wst, img, ty * tiles_x + tx, n0, t);
+  }
+}
+
 }  // namespace
 
 #ifdef MVT_STAMPS
@@ -774,6 +967,18 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
     }                                                                                                                              \
   } while (0)
   const int nw8 = rows_nw8();
+  // wide 3x3 / stride-1 layers without normalise-on-load (conv2): one 512-thread workgroup per 8 x 32 pixel tile and 256-channel
+  // block, LDS-DMA staging (conv3x3_big_bf16).  MVT_CONV_BIG=0 keeps the 64-channel row tiles (read per call: A/B runs, tests)
+  if (ksize == 3 && stride == 1 && !in_stats && a.in_bf16 && st_ok && Cout % BG_BN == 0 && ((uintptr_t)in & 15) == 0 && Cin % 8 == 0 &&
+      ldw % 8 == 0 && ((uintptr_t)w & 15) == 0 && (long long)Cout * ldw * 2 < (1LL << 31) && (long long)H * W * Cin * 2 < (1LL << 31)) {
+    const char* e = getenv("MVT_CONV_BIG");
+    if (!e || atoi(e) != 0) {
+      const long long tiles = (long long)n * mvt_cdiv(Ho, TR) * mvt_cdiv(Wo, TC) * (Cout / BG_BN);
+      MVT_REQUIRE(tiles < (1LL << 31));
+      hipLaunchKernelGGL(conv3x3_big_bf16, dim3((unsigned)tiles), dim3(512), 0, stream, a);
+      return mvt_launch_status();
+    }
+  }
   if (ksize == 3 && stride == 1 && nw8 == 1 && Ho % 16 == 0) LAUNCH(2, 3, 1, 8);
   else if (ksize == 3 && stride == 1 && nw8 == 2) LAUNCH(1, 3, 1, 4);
   else if (ksize == 3 && stride == 1) LAUNCH(2, 3, 1, 4);

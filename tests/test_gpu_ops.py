@@ -217,6 +217,41 @@ def test_conv2d_bf16_activation_tensors(hip, cfg):
         assert torch.equal(parts[0], parts[1])
 
 
+@pytest.mark.parametrize("cfg", [(2, 16, 32, 416, 256), (1, 45, 80, 416, 256), (3, 21, 37, 64, 512), (1, 128, 128, 96, 256), (2, 8, 32, 32, 256)])
+def test_conv_big_tile_bit_identical(hip, cfg, monkeypatch):
+    """conv3x3_big_bf16 (one 512-thread workgroup per 8 x 32 pixel tile and 256-channel block, LDS-DMA staging, swizzled 64-B slots)
+    against the 64-channel row tiles it replaces on the wide 3 x 3 / stride-1 layers without normalise-on-load (BasicEncoder.conv2,
+    spatracker/blocks.py:246): same accumulation order, same epilogue -> identical outputs and InstanceNorm partials, bit for bit.
+    Image sizes that leave partial tiles in both directions (45 x 80 is the C5 shard's feature map), one tile exactly, two channel
+    blocks; and the values themselves against an fp64 convolution of the same bf16 operands."""
+    n, H, W, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = (torch.randn(n, H, W, Cin, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    hi, _ = split(hip, G(pad_w(w.reshape(Cout, -1))), False)
+    slots = hip.conv2d_stat_slots(H, W, Cin, 3, 3, 1, 1, False)
+    xin, bias = G(x), G(b)
+    outs, parts = [], []
+    for big in ("1", "0"):
+        monkeypatch.setenv("MVT_CONV_BIG", big)
+        out = torch.full((n, H, W, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+        part = torch.full((n * slots * Cout * 2,), float("nan"), device=DEV)
+        hip.conv2d_bf16(xin, hi, None, bias, out, n, H, W, Cin, Cout, 3, 3, 1, 1, Cout, out_partial=part)
+        torch.cuda.synchronize()
+        outs.append(out)
+        parts.append(part)
+    assert bool(torch.isfinite(outs[0].float()).all()) and bool(torch.isfinite(parts[0]).all())
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(parts[0], parts[1])
+    wb = w.to(torch.bfloat16).double().permute(0, 3, 1, 2)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), wb, b.double(), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(outs[0].float(), ref) < 6e-3  # (the output's own bf16 rounding)
+    # the fused statistics: sums over the tiles' slots = sums over the image
+    ps = parts[0].reshape(n, slots, Cout, 2).double().sum(1).cpu()
+    assert (ps[..., 0] - ref.sum((1, 2))).abs().max() / ref.sum((1, 2)).abs().max() < 1e-4
+
+
 def test_encoder_elementwise_bf16_tensors(hip):
     g = torch.Generator().manual_seed(77)
     n, Hh, Ww, C = 2, 12, 20, 96

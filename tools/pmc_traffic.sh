@@ -5,6 +5,6 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o $c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/$c.log 2>&1 || exit 1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o $c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-corr-calibration > $out/$c.log 2>&1 || exit 1
 done
 ls $out/*

@@ -7,7 +7,7 @@ root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench.json 2> $out/trace.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-corr-calibration > $out/bench.json 2> $out/trace.err || exit 1
 f=$(find $out/trace -name '*kernel_stats.csv' | head -1)
 cp $f $root/gpurun_out/${name}_kernel_stats.csv
 python3 - <<PY
