@@ -96,9 +96,14 @@ int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const uns
  * activations in bf16 -- its big layers are HBM-bound, and the MFMA operands are bf16 anyway:
  *   MVT_IO_IN_BF16  `in` is bf16 [n][H][W][Cin]   (Cin % 32 == 0; the stem always reads fp32)
  *   MVT_IO_OUT_BF16 `out` is bf16 [n][Ho][Wo][ldo] (rounded to nearest even from the fp32 accumulator; the statistics
- *                   in out_partial are taken before the rounding) */
+ *                   in out_partial are taken before the rounding)
+ *   MVT_IO_SHORT_WG keep every workgroup short-lived: the wide 3x3 layers (Cout % 256 == 0, no normalise-on-load) otherwise run as
+ *                   one 512-thread, 144-KiB-LDS workgroup per CU and pixel tile (conv3x3_big_bf16, ~100 us each), which starves
+ *                   kernels of OTHER streams of CU slots while it runs -- set it for launches that share the GPU with latency-bound
+ *                   work (the encoder blocks that run beside the refinement windows).  Results are bit-identical either way. */
 #define MVT_IO_IN_BF16 1
 #define MVT_IO_OUT_BF16 2
+#define MVT_IO_SHORT_WG 4
 int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad, int split /* wt_lo != NULL */);
 int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
                     void* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
@@ -518,6 +523,7 @@ typedef struct mvt_conv_weights {
 } mvt_conv_weights;
 typedef struct mvt_encoder_weights {
   int latent_dim;
+  int short_workgroups; /* != 0: every convolution with MVT_IO_SHORT_WG (the call shares the GPU with other streams) */
   mvt_conv_weights conv[MVT_ENCODER_CONVS];
 } mvt_encoder_weights;
 long long mvt_encoder_workspace_bytes(int n, int H, int W, int latent_dim); /* host; -1 on bad arguments */

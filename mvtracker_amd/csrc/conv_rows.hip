@@ -27,15 +27,18 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // Diagnostic build only (-DMVT_STAMPS, tools/stamp_conv.py): s_memtime at the phase boundaries of two workgroups, one slot per
 // (workgroup, wave, stamp), in a buffer of its own.  No stamp executes in the shipped library.
 #ifdef MVT_STAMPS
-__device__ unsigned long long mvt_conv_stamp_buf[2 * 4 * 128];
+#ifndef MVT_STAMP_WG
+#define MVT_STAMP_WG 2000
+#endif
+__device__ unsigned long long mvt_conv_stamp_buf[2 * 8 * 128];
 #define CSTAMP(i)                                                                                                  \
   do {                                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     unsigned long long t_;                                                                                         \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
-    if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 2000) && (i) < 128)                           \
-      mvt_conv_stamp_buf[((blockIdx.x ? 1 : 0) * 4 + (threadIdx.x >> 6)) * 128 + (i)] = t_;                        \
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == MVT_STAMP_WG) && (i) < 128)                           \
+      mvt_conv_stamp_buf[((blockIdx.x ? 1 : 0) * 8 + (threadIdx.x >> 6)) * 128 + (i)] = t_;                        \
   } while (0)
 #else
 #define CSTAMP(i) \
@@ -841,48 +844,81 @@ __global__ __launch_bounds__(512, 2) void conv3x3_big_bf16(RowsArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // Software pipeline over the stages (stage = chunk c, filter row kh: six groups g = (kw, k-step) of eight MFMAs per wave).  The
+  // barrier of a stage sits between its groups 4 and 5: by then every fragment of the stage is in registers (group 5's reads were
+  // issued ahead of group 4's MFMAs), so the stage's buffers are free, and the wave's DMAs of the next stage have landed (counted
+  // vmcnt); BEHIND the barrier the first fragments of the next stage are requested and group 5's MFMAs cover their LDS round trip.
+  // The next stage's weights are requested behind groups 0-2, the next chunk's patch (kh = 0 only) behind groups 3-4 -- it is first
+  // read three stages later, so the wait of its own stage leaves it in flight (vmcnt(3): requests retire in order).
+  bf16x8 a[2][TM], bb[2][TN];
+  auto read_group = [&](int set, int g, int kh, const unsigned char* Pc, const unsigned char* Wc) {
+    const int kw = g >> 1, ks = g & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      a[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pc + pa[kw][ks] + (i + kh) * BG_PROW));
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      bb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wc + wl[ks] + kw * (BG_BN * 64) + j * 2048));
+  };
+  auto mfma_group = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], bb[set][j], acc[i][j], 0, 0, 0);
+  };
+  CSTAMP(0);
+#ifdef MVT_BIG_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the second-dispatched half loses every arbitration against its older SIMD partner
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_group(0, 0, 0, Pb, Wb);
   for (int c = 0; c < nchunk; ++c) {
     const unsigned char* const Pc = Pb + (c & 1) * BG_PBYTES;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int stage = 3 * c + kh;
-      // every wave's DMAs of this stage have landed (its own vmcnt(0), then the barrier), and every wave is done reading the
-      // buffers the next stage's DMAs overwrite (its MFMAs consumed those reads before it got here)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
       const int stage_n = stage + 1 < 3 * nchunk ? stage + 1 : stage, chunk_n = c + 1 < nchunk ? c + 1 : c;  // sources of the requests
       const unsigned char* const Wc = Wb + (stage & 1) * BG_WBYTES;
-      bf16x8 a[2][TM], bb[2][TN];
-      auto read_group = [&](int set, int g) {
-        const int kw = g >> 1, ks = g & 1;
+      // (group g's fragments sit in set g & 1: six groups per stage keep the parity across stages)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          a[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pc + pa[kw][ks] + (i + kh) * BG_PROW));
+      for (int g = 0; g < 5; ++g) {
+        read_group((g + 1) & 1, g + 1, kh, Pc, Wc);
+#ifdef MVT_BIG_EARLY
+        if (g == 0) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wc + wl[ks] + kw * (BG_BN * 64) + j * 2048));
-      };
-      read_group(0, 0);
+          for (int i = 0; i < 6; ++i) dma_weight(stage_n, stage + 1, i);
+        } else if (g == 1 && kh == 0) {
 #pragma unroll
-      for (int g = 0; g < 6; ++g) {
-        // the next group's fragments are requested before this group's MFMAs issue (pinned: left free, the scheduler sinks every
-        // read to just ahead of its first use and each group of four MFMAs waits out an LDS round trip); the stage's DMA
-        // requests are spread over the groups: weights of the next stage behind groups 0-2, the next chunk's patch behind 3-5
-        if (g + 1 < 6) read_group((g + 1) & 1, g + 1);
+          for (int i = 0; i < 3; ++i) dma_patch1(chunk_n, c + 1, i);
+        }
+#else
         if (g < 3) {
           dma_weight(stage_n, stage + 1, 2 * g);
           dma_weight(stage_n, stage + 1, 2 * g + 1);
+        } else if (kh == 0) {
+          dma_patch1(chunk_n, c + 1, g == 3 ? 0 : 2);
+          if (g == 3) dma_patch1(chunk_n, c + 1, 1);
         }
-        if (g >= 3 && kh == 0) dma_patch1(chunk_n, c + 1, g - 3);
+#endif
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][i], bb[g & 1][j], acc[i][j], 0, 0, 0);
+        mfma_group(g & 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (stage < 12) CSTAMP(1 + 10 * stage + g);
       }
+      if (kh == 0) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (stage < 12) CSTAMP(1 + 10 * stage + 5);
+      __builtin_amdgcn_s_barrier();
+      if (stage < 12) CSTAMP(1 + 10 * stage + 6);
+      read_group(0, 0, kh == 2 ? 0 : kh + 1, kh == 2 ? Pb + ((c + 1) & 1) * BG_PBYTES : Pc, Wb + ((stage + 1) & 1) * BG_WBYTES);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (stage < 12) CSTAMP(1 + 10 * stage + 7);
     }
   }
+  CSTAMP(124);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done with the patch / weight buffers: the staging tiles reuse the patch buffers
   // this wave's part of the statistics table (its rows x its channels; rows past the image stay zero) -- written below by the same wave
@@ -890,20 +926,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_big_bf16(RowsArgs p) {
 
   epilogue_rows<TM, TN, false, true, BG_BN>(acc, p, img, Ho, Wo, y0 + wm * TM, x0, n0 + wn * 64, tiles_x, tx, lane,
                                              reinterpret_cast<unsigned short*>(Pb) + wave * stage_elems<TN>(), wst + wn * 64 * 2, wm * TM);
+  CSTAMP(125);
   if (p.out_part) {
     __syncthreads();
     write_tile_stats<TR, BG_BN>(p, wst, img, ty * tiles_x + tx, n0, t);
   }
+  CSTAMP(126);
 }
 
 }  // namespace
 
 #ifdef MVT_STAMPS
 extern "C" int mvt_debug_read_conv_stamps(unsigned long long* host) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(mvt_conv_stamp_buf), sizeof(unsigned long long) * 2 * 4 * 128) == hipSuccess ? MVT_OK : MVT_ERR_HIP_BASE;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(mvt_conv_stamp_buf), sizeof(unsigned long long) * 2 * 8 * 128) == hipSuccess ? MVT_OK : MVT_ERR_HIP_BASE;
 }
 extern "C" int mvt_debug_clear_conv_stamps() {
-  static unsigned long long z[2 * 4 * 128];
+  static unsigned long long z[2 * 8 * 128];
   return hipMemcpyToSymbol(HIP_SYMBOL(mvt_conv_stamp_buf), z, sizeof(z)) == hipSuccess ? MVT_OK : MVT_ERR_HIP_BASE;
 }
 #endif
@@ -969,7 +1007,7 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
   const int nw8 = rows_nw8();
   // wide 3x3 / stride-1 layers without normalise-on-load (conv2): one 512-thread workgroup per 8 x 32 pixel tile and 256-channel
   // block, LDS-DMA staging (conv3x3_big_bf16).  MVT_CONV_BIG=0 keeps the 64-channel row tiles (read per call: A/B runs, tests)
-  if (ksize == 3 && stride == 1 && !in_stats && a.in_bf16 && st_ok && Cout % BG_BN == 0 && ((uintptr_t)in & 15) == 0 && Cin % 8 == 0 &&
+  if (ksize == 3 && stride == 1 && !in_stats && !(io_flags & MVT_IO_SHORT_WG) && a.in_bf16 && st_ok && Cout % BG_BN == 0 && ((uintptr_t)in & 15) == 0 && Cin % 8 == 0 &&
       ldw % 8 == 0 && ((uintptr_t)w & 15) == 0 && (long long)Cout * ldw * 2 < (1LL << 31) && (long long)H * W * Cin * 2 < (1LL << 31)) {
     const char* e = getenv("MVT_CONV_BIG");
     if (!e || atoi(e) != 0) {

@@ -92,8 +92,8 @@ static int encoder_run(const mvt_encoder_weights* w, const float* x4, const void
       MVT_REQUIRE(slots > 0);
       pp = part;
     }
-    ENC_TRY(mvt_conv2d_bf16(in, cw.w, nullptr, cw.b, out, n, hh, ww, cin, cout, k, k, stride, pad, ld_out, MVT_ACT_NONE, io_in | io_out,
-                            in_stats, pp, stream));
+    ENC_TRY(mvt_conv2d_bf16(in, cw.w, nullptr, cw.b, out, n, hh, ww, cin, cout, k, k, stride, pad, ld_out, MVT_ACT_NONE,
+                            io_in | io_out | (w->short_workgroups ? MVT_IO_SHORT_WG : 0), in_stats, pp, stream));
     if (st_out) {
       *st_out = new_st();
       ENC_TRY(mvt_instnorm_finish_slots(pp, slots, *st_out, n, (long long)ho * wo, cout, stream));

@@ -1,5 +1,5 @@
 // Library introspection entry points.
 #include "common.h"
 
-extern "C" int mvt_abi_version(void) { return 6; }
+extern "C" int mvt_abi_version(void) { return 7; }
 extern "C" const char* mvt_build_arch(void) { return "gfx950"; }

@@ -162,7 +162,7 @@ def _call(name, *args):
         raise HipError(f"{name} failed with code {rc}" + (" (arguments rejected)" if rc == 1 else " (HIP launch error)"))
 
 
-IO_IN_BF16, IO_OUT_BF16 = 1, 2
+IO_IN_BF16, IO_OUT_BF16, IO_SHORT_WG = 1, 2, 4
 
 
 def _io(t_in, t_out=None):
@@ -210,9 +210,11 @@ def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False) -> int:
 
 
 def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=ACT_NONE, in_stats=None,
-                out_partial=None):
+                out_partial=None, short_wg=False):
+    """``short_wg`` (MVT_IO_SHORT_WG): the launch shares the GPU with other streams -- keep every workgroup short-lived (the wide
+    3x3 layers then run on the 64-channel row tiles instead of one 512-thread workgroup per CU; identical results)."""
     _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
-          ldo, act, _io(x, out), _ptr(in_stats), _ptr(out_partial), _stream())
+          ldo, act, _io(x, out) | (IO_SHORT_WG if short_wg else 0), _ptr(in_stats), _ptr(out_partial), _stream())
 
 
 def instnorm_finish_slots(partial, slots, mean_rstd, n, HW, Cc):
@@ -609,7 +611,7 @@ class ConvWeights(C.Structure):
 
 class EncoderWeights(C.Structure):
     """mvt_encoder_weights (host struct of device pointers; keep the tensors referenced)."""
-    _fields_ = [("latent_dim", C.c_int), ("conv", ConvWeights * ENCODER_CONVS)]
+    _fields_ = [("latent_dim", C.c_int), ("short_workgroups", C.c_int), ("conv", ConvWeights * ENCODER_CONVS)]
 
 
 def encoder_workspace_bytes(n, H, W, Cc) -> int:

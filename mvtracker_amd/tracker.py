@@ -157,6 +157,12 @@ class MVTracker(nn.Module):
         self.encoder_streams = int(os.environ.get("MVT_ENC_STREAMS", "2"))  # 2: the chunks of an encoder call alternate between two streams
         self.presearch = os.environ.get("MVT_PRESEARCH", "1") != "0"  # first searches of new tracks beside the first encoder block
         self.stem_reads_clip = os.environ.get("MVT_STEM_RGB", "1") != "0"  # composite encoder: the stem reads the planar clip itself
+        # the wide conv2 as one 512-thread workgroup per CU (conv3x3_big_bf16) also for the encoder blocks that run on the second
+        # stream BESIDE the refinement windows: "0" never (its ~100-us workgroups starve the windows' kernels -- above all the
+        # latency-bound correlation gather -- of CU slots), "1" always, "auto": when the encoder, not the windows, bounds the call
+        # (the second stream has more than twice the images of the first block; BASELINE config C5: -6 % per step)
+        self.wide_conv_shared = os.environ.get("MVT_CONV_BIG_SHARED", "auto")
+        self._shared_gpu = False  # set around the encoder calls issued beside the windows
         self.defer_encoder = os.environ.get("MVT_ENC_DEFER", "0") != "0"  # one block of later frames per window on the side stream (A/B: no gain at C3)
         self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
         self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
@@ -338,9 +344,12 @@ class MVTracker(nn.Module):
                 names += [f"fnet.layer{li}.0.conv1", f"fnet.layer{li}.0.conv2", f"fnet.layer{li}.0.downsample.0" if li > 1 else f"fnet.layer{li}.0.conv1",
                           f"fnet.layer{li}.1.conv1", f"fnet.layer{li}.1.conv2"]
             names += ["fnet.conv2", "fnet.conv3"]
+            ews = hip.EncoderWeights()  # the same weights for calls that share the GPU with the refinement windows (MVT_IO_SHORT_WG)
+            ews.latent_dim, ews.short_workgroups = self.latent_dim, 1
             for i, nm in enumerate(names):  # (layer 1 has no downsample conv: slot 3 repeats a valid pointer and is never used)
                 ew.conv[i].w, ew.conv[i].b = pk[nm][0][0].data_ptr(), pk[nm][1].data_ptr()
-            pk["encoder_struct"] = ew
+                ews.conv[i].w, ews.conv[i].b = ew.conv[i].w, ew.conv[i].b
+            pk["encoder_struct"], pk["encoder_struct_shared"] = ew, ews
         pk["ffeats_norm"] = (sd["ffeats_norm.weight"].contiguous(), sd["ffeats_norm.bias"].contiguous())
         lin("ffeats_updater.0")
         pk["vis"] = (sd["vis_predictor.0.weight"].reshape(-1).contiguous(), sd["vis_predictor.0.bias"].contiguous())
@@ -441,7 +450,8 @@ class MVTracker(nn.Module):
         if isinstance(wt, tuple):
             slots = hip.conv2d_stat_slots(H, W, cin, k, k, stride, pad, wt[1] is not None) if (stats and self.fuse_norm) else 0
             part = torch.empty(n * slots * cout * 2, device=x.device) if slots else None
-            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo, in_stats=in_stats, out_partial=part)
+            hip.conv2d_bf16(x, wt[0], wt[1], b, out, n, H, W, cin, cout, k, k, stride, pad, ldo, in_stats=in_stats, out_partial=part,
+                            short_wg=self._shared_gpu)
             if slots:
                 st = torch.empty(n, cout, 2, device=x.device)
                 hip.instnorm_finish_slots(part, slots, st, n, Ho * Wo, cout)
@@ -493,16 +503,17 @@ class MVTracker(nn.Module):
         encoder's stem reads directly -- -> writes (n, H/4, W/4, C) into ``out_rows``."""
         C = self.latent_dim
         composite = "encoder_struct" in pk and out_rows.is_contiguous()
+        est = "encoder_struct_shared" if self._shared_gpu else "encoder_struct"
         if isinstance(x4, _ClipImages):
             src = x4
             if composite and self.stem_reads_clip:  # mvt_encoder_forward_rgb: no (n,H,W,4) staging tensor, one launch less
                 ws = self._workspace(hip.encoder_workspace_bytes(n, H, W, C), src.rgbs.device)
-                return hip.encoder_forward_rgb(pk["encoder_struct"], src.rgbs, src.V, src.T, src.img0, n, H, W, out_rows, C, ws)
+                return hip.encoder_forward_rgb(pk[est], src.rgbs, src.V, src.T, src.img0, n, H, W, out_rows, C, ws)
             x4 = torch.empty(n, H, W, 4, device=src.rgbs.device)
             hip.rgb_images_to_nhwc4(src.rgbs, x4, src.V, src.T, H, W, src.img0, n)
         if composite:  # the whole CNN as ONE library call (mvt_encoder_forward)
             ws = self._workspace(hip.encoder_workspace_bytes(n, H, W, C), x4.device)
-            return hip.encoder_forward(pk["encoder_struct"], x4, n, H, W, out_rows, C, ws)
+            return hip.encoder_forward(pk[est], x4, n, H, W, out_rows, C, ws)
         hs, ws = H // self.stride, W // self.stride
         x, h, w, st = self._conv(pk, "fnet.conv1", x4, n, H, W, 4, 64, 7, 2, 3, stats=True)
         lazy_stem = self.fuse_norm and self.precision == "bf16"  # relu(IN(stem)) is applied by its two consumers instead
@@ -598,10 +609,19 @@ class MVTracker(nn.Module):
         streams = [self._side_stream(dev)]
         for st in streams:
             st.wait_stream(torch.cuda.current_stream(dev))
+        # these blocks run BESIDE the refinement windows: short-lived workgroups only, unless the encoder bounds the call anyway
+        V = rgbs.shape[0]
+        first_block = max(1, min(T, S)) * V
+        side_images = sum(min(T, a + S // 2) - a for a in firsts) * V
+        big = self.wide_conv_shared == "1" or (self.wide_conv_shared == "auto" and side_images > 2 * first_block)
         for i, a in enumerate(firsts):
             st = streams[i % len(streams)]
             with torch.cuda.stream(st):
-                self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
+                self._shared_gpu = not big
+                try:
+                    self.fill_frame_features(store, rgbs, a, min(T, a + S // 2))
+                finally:
+                    self._shared_gpu = False
                 ev = torch.cuda.Event()
                 ev.record(st)
                 pending.append((a, ev))

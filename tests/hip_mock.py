@@ -129,7 +129,7 @@ def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False):
     return Ho * Wo // 32 if (Ho * Wo) % 256 == 0 else 0
 
 
-def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0, in_stats=None, out_partial=None):
+def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0, in_stats=None, out_partial=None, short_wg=False):
     K = KH * 32 if Cin == 4 else KH * KW * Cin
     ld = (K + 63) // 64 * 64
     w = _w_from_bf16(wt_hi, wt_lo, Cout, ld).contiguous()

@@ -36,7 +36,7 @@ def test_ctypes_table_matches_header():
 
 def test_introspection_without_gpu():
     from mvtracker_amd import hip
-    assert hip.abi_version() == 6 and hip.build_arch() == "gfx950"
+    assert hip.abi_version() == 7 and hip.build_arch() == "gfx950"
 
 
 def test_ctypes_structs_match_header_layout(tmp_path):

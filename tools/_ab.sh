@@ -1,6 +1,8 @@
-python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "conv" 2>&1 | tail -5
-for big in 1 0; do
-  export MVT_CONV_BIG=$big; echo "== MVT_CONV_BIG=$big"
-  python tools/prof_conv.py 24 128 128 416 256 3 1 1 1 0
-  python tools/prof_conv.py 48 180 320 416 256 3 1 1 1 0
-done
+run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-corr-calibration | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['ms_per_step'],3), round(d['roofline_mfma']['encoder']['frac'],4), 'corr', round(r['frac'],3))"; }
+run MVT_CONV_BIG=0
+run MVT_CONV_BIG_SHARED=0
+run MVT_CONV_BIG_SHARED=0 MVT_ENC_STREAMS=1
+run MVT_CONV_BIG_SHARED=0 MVT_ENC_CHUNK=48
+run MVT_CONV_BIG_SHARED=1
+run MVT_CONV_BIG_SHARED=1 MVT_ENC_STREAMS=1
+run MVT_CONV_BIG=0

@@ -32,16 +32,18 @@ b = torch.randn(Cout, device=dev)
 slots = hip.conv2d_stat_slots(H, W, Cin, k, k, s, p, False)
 part = torch.empty(n * max(slots, 1) * Cout * 2, device=dev)
 st = torch.rand(n, Cin, 2, device=dev) + 0.5
-run = lambda: hip.conv2d_bf16(x, hi, None, b, out, n, H, W, Cin, Cout, k, k, s, p, Cout, in_stats=st, out_partial=part)
+norm = os.environ.get("STAMP_NORM", "1") != "0"
+run = lambda: hip.conv2d_bf16(x, hi, None, b, out, n, H, W, Cin, Cout, k, k, s, p, Cout, in_stats=st if norm else None, out_partial=part)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
 assert lib.mvt_debug_clear_conv_stamps() == 0
 run()
 torch.cuda.synchronize()
-buf = np.zeros(2 * 4 * 128, dtype=np.uint64)
+NWV = 8
+buf = np.zeros(2 * NWV * 128, dtype=np.uint64)
 assert lib.mvt_debug_read_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-buf = buf.reshape(2, 4, 128).astype(np.int64)
+buf = buf.reshape(2, NWV, 128).astype(np.int64)
 names = {0: "start", 120: "loop end", 121: "epilogue", 122: "end"}
 for c in range(14):
     names.update({1 + 8 * c: f"c{c} top", 2 + 8 * c: f"c{c} patch st"})
@@ -52,10 +54,10 @@ for wg in range(2):
         continue
     t0 = buf[wg][buf[wg] > 0].min()
     print(f"workgroup slot {wg}: cycles since the first stamp / delta, per wave")
-    prev = {w_: None for w_ in range(4)}
+    prev = {w_: None for w_ in range(NWV)}
     for i in [i for i in range(128) if (buf[wg, :, i] > 0).any()]:
         cells = []
-        for w_ in range(4):
+        for w_ in range(NWV):
             v = buf[wg, w_, i]
             if v <= 0:
                 cells.append("      -      ")
