@@ -266,7 +266,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timing["on"] = False
-    model.check_finite()
+    runner.check_finite_collective()  # (every rank joins: a rank raising alone would strand its peers)
     # Calibration of the HIP-event timing of the correlation kernel, outside the timed region, with the operands of the last launch
     # and nothing else on the chip: (a) the same launch 20 x back to back inside ONE event pair -> its duration alone, launch gaps
     # included, no event cost (the ~225 MB it touches may stay cache-resident between the repeats: a WARM figure); (b) 20 single

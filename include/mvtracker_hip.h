@@ -491,8 +491,10 @@ typedef struct mvt_updater_weights {
   int fuse_attention; /* bit 0: time attention, bit 1: point<-virtual, bit 2: virtual self attention run inside the block kernels
                          (mvt_attn_block_fused_bf16) instead of as separate launches; bit 3: unused (ignored); bit 4: the virtual<-point block
                          combines the key-split partials (MVT_ATTN_PARTIALS, no merge launch); bit 5 (with bits 1 and 2, >= 4096 point rows): the
-                         virtual-self block's second launch runs inside the point<-virtual block (MVT_ATTN_FRAME_CTX); results are
-                         bit-identical either way */
+                         virtual-self block's second launch runs inside the point<-virtual block (MVT_ATTN_FRAME_CTX).  Bits 4 and 5 only move
+                         WHERE partial sums are combined: bit-identical with and without.  Bits 0-2 change the attention arithmetic (one
+                         softmax pass over all key blocks, the time attention of a tile as one block-diagonal unit per head): results agree
+                         with the separate launches to bf16 rounding (max ~7e-3 of the output scale), not bit for bit */
   const float* virtual_tokens; /* [n_virtual][hidden] */
   mvt_lin_rows input_transform, flow0, flow2, flow4;
   mvt_updater_block time_blk[MVT_UPDATER_MAX_DEPTH], v2p[MVT_UPDATER_MAX_DEPTH], vself[MVT_UPDATER_MAX_DEPTH], p2v[MVT_UPDATER_MAX_DEPTH];

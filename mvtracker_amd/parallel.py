@@ -143,7 +143,9 @@ class ShardedTracker:
         self.last_store = store
         res = m(rgbs, depths, query_points[:, a:b], intrs, extrs, iters=iters, frame_store=store)
         if not gather_output:
-            return res  # (the caller owns the deferred NaN check: model.check_finite())
+            # (the caller owns the deferred NaN check -- and with more than one rank it must be check_finite_collective(): a rank
+            #  that raised on model.check_finite() alone would leave its peers blocked in their next collective)
+            return res
         per = (N + world - 1) // world
         traj = torch.zeros(per, T, 3, device=rgbs.device)
         vis = torch.zeros(per, T, device=rgbs.device)
@@ -154,10 +156,18 @@ class ShardedTracker:
         # The NaN guard (mvtracker.py:401-404) is a COLLECTIVE decision: a rank that raised on its own shard's flag would leave
         # its peers blocked in the next collective.  Every rank joins every collective of the call first, the per-shard flags
         # are max-reduced, and then all ranks raise (or none does) together -- one host read per call, after the last collective.
-        flag = getattr(m, "last_nan_flag", None)
-        if flag is not None:
+        self.check_finite_collective()
+        return {"traj_e": traj, "vis_e": vis, "feat_init": res["feat_init"]}
+
+    def check_finite_collective(self):
+        """The deferred NaN guard of the last call as a COLLECTIVE decision (the only safe check after ``gather_output=False`` at
+        world > 1): the per-shard flags are max-reduced and then every rank raises, or none does.  Every rank must call it."""
+        world, _ = self._world()
+        flag = getattr(self.model, "last_nan_flag", None)
+        if flag is None:
+            return
+        if world > 1 or (dist.is_available() and dist.is_initialized()):
             flag = flag.clone()
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-            if int(flag.item()) != 0:
-                raise FloatingPointError("Got NaN values in coords (on at least one query shard), perhaps the training exploded")
-        return {"traj_e": traj, "vis_e": vis, "feat_init": res["feat_init"]}
+        if int(flag.item()) != 0:
+            raise FloatingPointError("Got NaN values in coords (on at least one query shard), perhaps the training exploded")

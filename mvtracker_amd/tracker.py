@@ -150,7 +150,9 @@ class MVTracker(nn.Module):
         self.bf16_activations = os.environ.get("MVT_BF16_ACT", "1") != "0"  # bf16 mode: encoder activations stored as bf16
         self.bf16_store = os.environ.get("MVT_BF16_STORE", "1") != "0"  # bf16 mode: bf16 feature rows in the frame store
         # attention inside the block kernels: bit 0 time, bit 1 point<-virtual, bit 2 virtual self; bit 4: the virtual<-point block
-        # combines the key-split partials in its prologue, no merge launch (all variants are bit-identical to the separate launches)
+        # combines the key-split partials in its prologue, no merge launch; bit 5: the virtual-self block's pass 2 inside the
+        # point<-virtual block.  Bits 4 / 5 are bit-identical to the launches they replace; bits 0-2 agree with the separate attention
+        # launches to bf16 rounding only (single-pass softmax, block-diagonal time attention: round 3)
         self.fuse_attention = int(os.environ.get("MVT_FUSE_ATTN", "55"))
         self.seed_across_windows = os.environ.get("MVT_SEED_WINDOWS", "1") != "0"  # previous window's neighbours seed the first scan
         self.encoder_chunk_images = int(os.environ.get("MVT_ENC_CHUNK", "0"))  # images per encoder call (0: max(16, V * S/2))
@@ -163,6 +165,9 @@ class MVTracker(nn.Module):
         # (the second stream has more than twice the images of the first block; BASELINE config C5: -6 % per step)
         self.wide_conv_shared = os.environ.get("MVT_CONV_BIG_SHARED", "auto")
         self._shared_gpu = False  # set around the encoder calls issued beside the windows
+        # MVT_SYNC_DEBUG=1: synchronise the whole device at every cross-stream hand-over of a call ("hand-over
+        # table"): if results change with it, an event / wait_stream is missing somewhere (tests: bit-identical with and without)
+        self.sync_debug = os.environ.get("MVT_SYNC_DEBUG", "0") != "0"
         self.defer_encoder = os.environ.get("MVT_ENC_DEFER", "0") != "0"  # one block of later frames per window on the side stream (A/B: no gain at C3)
         self.knn_one_launch = os.environ.get("MVT_KNN_ONE_LAUNCH", "1") != "0"  # seeded scans: one wave per (track, frame), no merge launch
         self.composite_encoder = os.environ.get("MVT_COMPOSITE_ENCODER", "1") != "0"  # the CNN as one library call (bf16 mode)
@@ -552,7 +557,8 @@ class MVTracker(nn.Module):
         cur = torch.cuda.current_stream(dev) if two else None
         helper = self._helper_stream(dev) if two else None
         if two:
-            helper.wait_stream(cur)
+            helper.wait_stream(cur)  # hand-over H1: the helper stream reads the clip / writes store rows the caller's stream owns
+            self._handover(dev)
         joins = []
         for ci, a in enumerate(starts):
             n = min(images_per_chunk, i1 - a)
@@ -569,7 +575,9 @@ class MVTracker(nn.Module):
                 after_first_chunk()
                 after_first_chunk = None
         for ev in joins:
-            cur.wait_event(ev)
+            cur.wait_event(ev)  # hand-over H2: the helper's chunks (store rows) back to the caller's stream
+        if joins:
+            self._handover(dev)
         if after_first_chunk is not None:
             after_first_chunk()
 
@@ -585,6 +593,11 @@ class MVTracker(nn.Module):
         self.encode_images(rgbs, t0 * V, t1 * V, _Shifted(flat, out_t0 * V), images_per_chunk=max(1, images_per_chunk // V) * V,
                            after_first_chunk=after_first_chunk)
         return F0
+
+    def _handover(self, dev):
+        """Debug hook at every point where one stream starts consuming what another produced (see ``sync_debug``)."""
+        if self.sync_debug and dev.type == "cuda":
+            torch.cuda.synchronize(dev)
 
     # ------------------------------------------------------------------ frame store (model_utils.py:420-482)
     def _helper_stream(self, dev):
@@ -608,7 +621,8 @@ class MVTracker(nn.Module):
         #  of the first block measured +0.5 ms -- beside the updater their concurrency only adds contention)
         streams = [self._side_stream(dev)]
         for st in streams:
-            st.wait_stream(torch.cuda.current_stream(dev))
+            st.wait_stream(torch.cuda.current_stream(dev))  # hand-over H3: the store (allocated / geometry written on the caller's stream)
+        self._handover(dev)
         # these blocks run BESIDE the refinement windows: short-lived workgroups only, unless the encoder bounds the call anyway
         V = rgbs.shape[0]
         first_block = max(1, min(T, S)) * V
@@ -1138,7 +1152,9 @@ class MVTracker(nn.Module):
             K, L = self.corr_neighbors, self.corr_n_levels
             side = self._side_stream(dev)
             main_s = torch.cuda.current_stream(dev)
+            # hand-over H4: point clouds / tile boxes / sorted query rows (all enqueued on the caller's stream BEFORE the geometry event)
             side.wait_stream(main_s) if "geo_event" not in st else side.wait_event(st["geo_event"])
+            self._handover(dev)
             with torch.cuda.stream(side):
                 ww, q0 = w, 0
                 P0 = st["P"][0]
@@ -1195,14 +1211,16 @@ class MVTracker(nn.Module):
             p1 = int(np.searchsorted(qt_s, w + S, side="left"))  # number of queries with t < w+S (:538-540)
             assert p1 > 0
             while pending and pending[0][0] < w + S:  # the frames this window reads must have left the encoder
-                torch.cuda.current_stream(dev).wait_event(pending.pop(0)[1])
+                torch.cuda.current_stream(dev).wait_event(pending.pop(0)[1])  # hand-over H5: feature rows encoded on the second stream
+                self._handover(dev)
             if side_chunks:
                 # one block of later frames per window: block j is what window j + 1 will read, so it is encoded WHILE window j is
                 # refined -- its convolutions fill the CUs the 64 virtual tracks' kernels leave idle -- instead of all blocks
                 # piling onto the first window (which then runs at half speed while the last windows run alone)
                 self._encode_on_side_stream(store, rgbs, [side_chunks.pop(0)], pending)
             if "event" in pre:  # the searches issued ahead of time on the second stream
-                torch.cuda.current_stream(dev).wait_event(pre.pop("event"))
+                torch.cuda.current_stream(dev).wait_event(pre.pop("event"))  # hand-over H6: neighbour buffers / 1-NN keys (record_stream'd)
+                self._handover(dev)
             pre_w = pre.get(w)
             if p1 > p0 and pre_w is not None:  # feature init from the 1-NN keys scanned ahead of time
                 P0 = store["P"][0]
@@ -1241,7 +1259,7 @@ class MVTracker(nn.Module):
             w += S // 2
             p0 = p1
         for _, ev in pending:  # frames no window consumed: still join the side stream before the inputs are released
-            torch.cuda.current_stream(dev).wait_event(ev)
+            torch.cuda.current_stream(dev).wait_event(ev)  # hand-over H7: the caller's inputs (read by the second stream) are released
         self.last_windows = windows
         self.last_vis_logits = vis_logit[None]
         self.last_nan_flag = nan_flag

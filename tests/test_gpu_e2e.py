@@ -883,6 +883,33 @@ def test_presearch_without_window_seeding(model, prec):
         assert torch.equal(t, t0) and torch.equal(v, v0), k
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_stream_handovers_sync_debug_bit_identical(model, golden, prec):
+    """MVT_SYNC_DEBUG (``sync_debug``): a device-wide synchronise at every cross-stream hand-over of a call (DESIGN.md section 5,
+    hand-over table H1-H7: helper-stream encoder chunks, second-stream encoder blocks, searches issued ahead of the encoder).  If an
+    event or wait_stream were missing, the synchronised run would differ from the free-running one (round 3 shipped such a race
+    for a day: the pre-searches read query rows gathered AFTER the event they waited for).  Three windows, late queries, every
+    overlap path on: identical results, bit for bit -- one run each, and the free-running run first (cold allocator, most overlap)."""
+    clip = synth.make_clip(44, V=2, T=24, H=128, W=128, N=40, late_queries=True, query_frames=(3, 7, 13))
+    a = args_of(clip, DEV)
+    with _with_precision(model, prec):
+        assert model.overlap_encoder and model.presearch and model.encoder_streams == 2
+        old = model.sync_debug
+        try:
+            model.sync_debug = False
+            r = model(*a, iters=3)
+            t0, v0 = r["traj_e"].clone(), r["vis_e"].clone()
+            model.sync_debug = True
+            r = model(*a, iters=3)
+            t1, v1 = r["traj_e"].clone(), r["vis_e"].clone()
+            torch.cuda.synchronize()
+        finally:
+            model.sync_debug = old
+    model.check_finite()
+    assert len(model.last_windows) == 3
+    assert torch.equal(t0, t1) and torch.equal(v0, v1)
+
+
 @pytest.mark.parametrize("shape", [(3, 64, 96), (2, 180, 320)])
 def test_composite_encoder_bit_identical(model, shape):
     """mvt_encoder_forward (the CNN's 56 launches sequenced inside the library over a caller workspace) against the same kernels
@@ -1053,10 +1080,37 @@ def test_forward_corr_options_golden(golden, name):
     m.check_finite()
     rel = np.abs(r["traj_e"].cpu().numpy() - ref).max() / np.abs(ref).max()
     verr = np.abs(r["vis_e"].cpu().numpy() - g[name + "_vis"]).max()
-    # Two windows with late queries on a seed that was NOT scanned for near-ties (a neighbour flip moves a
-    # multi-window run by ~1e-3): the end-to-end bar is the flip-level one, and every iteration of every window is checked
-    # teacher-forced at the strict bar below (indices bit-exact, correlation rows 5e-5, in this layout).
-    assert rel < 2e-3 and verr < 2e-2, (rel, verr)
+    print(f"corr options {name}: fp32 tracks rel {rel:.2e}, visibility {verr:.2e} vs the reference fixture")
+    if not (rel < 1e-4 and verr < 1e-3):
+        # Over the north-star bar: that is only acceptable as a NEIGHBOUR FLIP of the reference algorithm (two candidates whose
+        # distances differ by less than the fp32 noise of the track position exchange places in the ranking),
+        # and it has to be SHOWN, not assumed: trace both sides (the oracle reproduces this fixture to 1e-4,
+        # test_corr_options_end_to_end_oracle), find the first (window, iteration) whose neighbour lists differ, and require (a) that
+        # there is one, (b) that up to it every update agrees at the strict bar, (c) that the flipped lists hold the SAME points with
+        # at most a few ranks exchanged -- an indexing or arithmetic error would change the sets --, (d) the flip-level end-to-end bar.
+        cfg = O.TrackerConfig(**CORR_OPT_CASES[name])
+        tr, otr = [], {}
+        m(*a, iters=3, trace=tr)
+        with torch.no_grad():
+            ro = O.tracker_forward(O.make_weights(cfg, 0), cfg, *args_of(corr_opts_clip(g)), iters=3, knn_mode="exact", trace=otr)
+        assert np.abs(ro["traj_e"].numpy() - ref).max() / np.abs(ref).max() < 1e-4  # the oracle IS the reference here
+        first_flip, L = None, m.corr_n_levels
+        for wi, (wt, ow) in enumerate(zip(tr, otr["windows"])):
+            for it in range(len(wt["knn_idx"])):
+                for l in range(L):
+                    pi, oi = wt["knn_idx"][it][l].cpu().long(), ow["knn_idx"][it * L + l].permute(1, 0, 2)
+                    if not torch.equal(pi, oi) and first_flip is None:
+                        first_flip = (wi, it, l)
+                        bad = (pi != oi).any(-1)
+                        ps, os_ = pi[bad].sort(-1).values, oi[bad].sort(-1).values
+                        assert torch.equal(ps, os_), "the differing neighbour lists do not hold the same points: not a rank swap"
+                        assert int(bad.sum()) <= 4 and int((pi[bad] != oi[bad]).sum(-1).max()) <= 4, (int(bad.sum()), "lists differ")
+                if first_flip is None:  # identical neighbours so far: the update itself must agree tightly
+                    de = ((wt["delta"][it].cpu() - ow["delta"][it]).abs().max() / ow["delta"][it].abs().max()).item()
+                    assert de < 1e-3, (wi, it, de)
+        print(f"corr options {name}: first neighbour flip at (window, iteration, level) {first_flip}")
+        assert first_flip is not None, f"{name}: tracks {rel:.2e} off the reference fixture WITHOUT a neighbour flip"
+        assert rel < 2e-3 and verr < 2e-2, (rel, verr)
     w = _check_forward_trace(m, a, n_sample=10, iters=3)
     print(f"{name}: teacher-forced fcorr rows max abs err {w:.2e}")
     m.precision = "bf16"
