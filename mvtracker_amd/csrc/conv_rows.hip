@@ -23,6 +23,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // Diagnostic build only (-DMVT_STAMPS, tools/stamp_conv.py): s_memtime at the phase boundaries of two workgroups, one slot per
 // (workgroup, wave, stamp), in a buffer of its own.  No stamp executes in the shipped library.
@@ -429,14 +432,17 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
 
   f32x4 rp[NPL];   // fp32 tensors: 4 channels; bf16 tensors: 8 packed channels (bit pattern)
   u32x4 rw[NWF];
+  // (addresses = wave-uniform 64-bit base + UNSIGNED 32-bit lane offset in bytes: the saddr form of global_load.  As signed element
+  //  offsets every pg[i] / wg[i] was sign-extended into a register PAIR that lived through the whole main loop)
   auto load_patch = [&](int c0) {
     if (INB) {
+      const char* base = reinterpret_cast<const char*>(reinterpret_cast<const unsigned short*>(p.in) + in_img + c0);
 #pragma unroll
-      for (int i = 0; i < NPL; ++i)
-        rp[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(p.in) + in_img + pg[i] + c0);
+      for (int i = 0; i < NPL; ++i) rp[i] = *reinterpret_cast<const f32x4*>(base + (unsigned)(pg[i] * 2));
     } else {
+      const char* base = reinterpret_cast<const char*>(p.in + in_img + c0);
 #pragma unroll
-      for (int i = 0; i < NPL; ++i) rp[i] = *reinterpret_cast<const f32x4*>(p.in + in_img + pg[i] + c0);
+      for (int i = 0; i < NPL; ++i) rp[i] = *reinterpret_cast<const f32x4*>(base + (unsigned)(pg[i] * 4));
     }
   };
   auto norm4 = [&](f32x4 v, const f32x4& m, const f32x4& rs) {
@@ -464,6 +470,22 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
         if (sl >= G::NSLOT) continue;
         u32x4 w = __builtin_bit_cast(u32x4, rp[i]);
         if (p.in_stats) {
+#ifndef MVT_NO_PACKED_NORM
+          // Round 4 (the lever round 2 had to revert for 4-9 spilled registers; the loader's 32-bit lane offsets freed them): per
+          // 32-bit word = two channels, packed fp32 arithmetic -- v_pk_add_f32 with (-mean), v_pk_mul_f32 with rstd: the SAME two
+          // roundings as (x - mean) * rstd --, one v_cvt_pk_bf16_f32, and the ReLU as a packed 16-bit INTEGER max with 0 on the
+          // bf16 pair (a negative bf16 is a negative int16; rounding commutes with max(., 0)): 24 instead of 36 vector
+          // instructions per 16-byte piece, bit-identical results for every non-NaN input.
+          auto pair = [](unsigned ww, float nm0, float nm1, float r0, float r1) -> unsigned {
+            f32x2 v = (f32x2){__uint_as_float(ww << 16), __uint_as_float(ww & 0xFFFF0000u)};
+            v = (v + (f32x2){nm0, nm1}) * (f32x2){r0, r1};
+            s16x2 q = __builtin_bit_cast(s16x2, __builtin_convertvector(v, bf16x2));
+            q = __builtin_elementwise_max(q, (s16x2){0, 0});
+            return __builtin_bit_cast(unsigned, q);
+          };
+          w = (u32x4){pair(w[0], -sm0[0], -sm0[1], sr0[0], sr0[1]), pair(w[1], -sm0[2], -sm0[3], sr0[2], sr0[3]),
+                      pair(w[2], -sm1[0], -sm1[1], sr1[0], sr1[1]), pair(w[3], -sm1[2], -sm1[3], sr1[2], sr1[3])};
+#else
           f32x4 lo = (f32x4){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16),
                              __uint_as_float(w[1] & 0xFFFF0000u)};
           f32x4 hi = (f32x4){__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xFFFF0000u), __uint_as_float(w[3] << 16),
@@ -471,6 +493,7 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
           const u32x2 a = __builtin_bit_cast(u32x2, __builtin_convertvector(norm4(lo, sm0, sr0), bf16x4));
           const u32x2 c = __builtin_bit_cast(u32x2, __builtin_convertvector(norm4(hi, sm1, sr1), bf16x4));
           w = (u32x4){a[0], a[1], c[0], c[1]};
+#endif
         }
         if (!pk[i]) w = (u32x4){0u, 0u, 0u, 0u};  // zero padding applies after the normalisation
         *reinterpret_cast<u32x4*>(&Ps[sl * LDP + (f - sl * ppp) * cpp]) = w;
@@ -488,17 +511,20 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
       }
     }
   };
+  // (64-channel tiles of 256 threads: piece i of a thread is tap i of the same weight row -- one offset register instead of NWF)
+  constexpr bool WREG1 = BN == 64 && NT == 256 && NWF == KS;
   auto load_w = [&](int c0, int kh) {
     const int base = kh * KS * p.Cin + c0;
 #pragma unroll
-    for (int i = 0; i < NWF; ++i) rw[i] = *reinterpret_cast<const u32x4*>(p.w + wg[i] + base);
+    for (int i = 0; i < NWF; ++i)
+      rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.w + base + (WREG1 ? i * p.Cin : 0)) + (unsigned)(wg[WREG1 ? 0 : i] * 2));
   };
   auto store_w = [&]() {
 #pragma unroll
     for (int i = 0; i < NWF; ++i) {
       const int u = t + NT * i, row = u >> 2;
       if (row >= KS * BN) continue;
-      *reinterpret_cast<u32x4*>(&Ws[row * LDP + (u & 3) * 8]) = wk[i] ? rw[i] : (u32x4){0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(&Ws[row * LDP + (u & 3) * 8]) = wk[WREG1 ? 0 : i] ? rw[i] : (u32x4){0u, 0u, 0u, 0u};
     }
   };
 
@@ -545,6 +571,41 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
         load_w((c + 1) * CK, 0);
         load_patch((c + 1) * CK);
       }
+#ifdef MVT_ROWS_PIPE
+      // Round 4: the fragments of group g + 1 (a group = one tap, one 16-wide k-step: TM + TN reads, TM x TN MFMAs) are requested
+      // BEFORE the MFMAs of group g issue, in two register sets, and the order is pinned: left free, the scheduler sinks every read
+      // to just ahead of its first use and each group waits out an LDS round trip (in-kernel stamps: 2 000-2 300 cycles per 24
+      // MFMAs that occupy the pipe for 768).
+      {
+        constexpr int NG = KS * (CK / 16);
+        bf16x8 a[2][TM], bb[2][TN];
+        auto read_group = [&](int set, int g) {
+          const int kw = g / (CK / 16), ks = g % (CK / 16);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            a[set][i] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(Pl + ((G::row_step() * i + kh) * G::RS + G::tap_col(kw)) * LDP + ks * 16));
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            bb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + (kw * BN + j * 32) * LDP + ks * 16));
+        };
+        // (the last filter row of a chunk carries the next chunk's patch in registers -- 24 VGPRs, the kernel's pressure point at the
+        //  168 of three workgroups per CU: there a group's reads are issued right ahead of its own MFMAs, one set)
+        const bool AHEAD = MVT_ROWS_PIPE >= 2 || kh + 1 < KS || KS == 1;  // (compile time: kh is an unrolled loop index)
+        read_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (AHEAD && g + 1 < NG) read_group((g + 1) & 1, g + 1);
+          if (!AHEAD && g > 0) read_group(g & 1, g);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][i], bb[g & 1][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#else
 #pragma unroll
       for (int kw = 0; kw < KS; ++kw) {
 #pragma unroll
@@ -563,6 +624,7 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
       }
+#endif
       CSTAMP(4 + 8 * c + 2 * kh);
       __syncthreads();
     }
@@ -580,7 +642,11 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
   CSTAMP(121);
   if (p.out_part) {
     __syncthreads();
-    write_tile_stats<G::ROWS, BN>(p, wst, img, ty * tiles_x + tx, n0, t);
+    // (the thread index again, behind an opaque move: carried across the main loop, its byte offset was the one register the
+    //  kernel spilled at the 168 of three workgroups per CU)
+    int t2;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(t2) : "v"(threadIdx.x));
+    write_tile_stats<G::ROWS, BN>(p, wst, img, ty * tiles_x + tx, n0, t2);
   }
   CSTAMP(122);
 }

@@ -881,7 +881,8 @@ extern "C" int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, cons
   a.out_part = out_partial;
   a.a_bf16 = io_flags & MVT_IO_IN_BF16 ? 1 : 0;
   a.c_bf16 = io_flags & MVT_IO_OUT_BF16 ? 1 : 0;
-  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16 | MVT_IO_SHORT_WG)) == 0 && (!io_flags || !wt_lo));  // bf16 tensors: bf16 mode only
+  MVT_REQUIRE((io_flags & ~(MVT_IO_IN_BF16 | MVT_IO_OUT_BF16 | MVT_IO_SHORT_WG)) == 0);
+  MVT_REQUIRE(!(io_flags & (MVT_IO_IN_BF16 | MVT_IO_OUT_BF16)) || !wt_lo);  // bf16 tensors: bf16 mode only
   MVT_REQUIRE(!a.a_bf16 || (Cin % 32 == 0 && (uintptr_t)in % 8 == 0));                          // (the stem reads fp32 RGB)
   a.slots = mvt_conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, wt_lo != nullptr);
   MVT_REQUIRE(!out_partial || (a.slots > 0 && (wt_lo || act == MVT_ACT_NONE)));
