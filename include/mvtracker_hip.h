@@ -105,6 +105,17 @@ int mvt_gemm_bf16(const float* A, int lda, const unsigned short* w_hi, const uns
 #define MVT_IO_OUT_BF16 2
 #define MVT_IO_SHORT_WG 4
 int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int stride, int pad, int split /* wt_lo != NULL */);
+/* The first two convolutions of a strided ResidualBlock that read the block input (spatracker/blocks.py:84-128: conv1 = 3x3 / stride 2
+ * / pad 1 and downsample[0] = 1x1 / stride 2 of the SAME x) in ONE launch, bf16 mode, bf16 tensors: the downsample samples input
+ * pixel (2y, 2x) = the centre tap of the 3x3 window around output (y, x), so it is computed from the patch conv1 has staged, with its
+ * own weights wd [Cout][ldwd] (rows = cin), bias, output tensor and statistics -- one launch, one staging of the input and one
+ * InstanceNorm-finish fewer per block.  out3 / outd [n][Ho][Wo][ldo] bf16; part3 / partd [n][slots][Cout][2] with
+ * slots = mvt_conv2d_stat_slots(H, W, Cin, 3, 3, 2, 1, 0) for BOTH (both NULL: no statistics).  Cin % 32 == 0, Cout % 32 == 0.
+ * Values identical to the two separate mvt_conv2d_bf16 launches (same accumulation order); the downsample's statistics are cut
+ * into this kernel's 4-row tiles instead of the 1x1 kernel's 8-row tiles (another fixed summation order). */
+int mvt_conv3x3s2_down_bf16(const void* in, const unsigned short* w3, const float* b3, const unsigned short* wd, const float* bd,
+                            void* out3, void* outd, int n, int H, int W, int Cin, int Cout, int ldo, float* part3, float* partd,
+                            void* stream);
 int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
                     void* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
                     int act, int io_flags, const float* in_stats, float* out_partial, void* stream);

@@ -63,6 +63,13 @@ struct RowsArgs {
   const void* rgb;
   int rgb_u8, rgb_V, rgb_T;
   long long rgb_img0;
+  // fused downsample branch (DS, the stride-2 3x3 kernel): the ResidualBlock's 1x1 / stride-2 convolution of the SAME input
+  // (blocks.py:112-128) = the centre tap of every output pixel with its own weights [Cout][ldw2], bias, output and statistics
+  const unsigned short* w2;
+  const float* bias2;
+  float* out2;
+  float* out_part2;
+  int ldw2;
 };
 
 constexpr int TR = 8;            // output rows per workgroup (stem and the stride-1 3x3 kernels)
@@ -371,8 +378,9 @@ template <int TM, int KS, int S, int NW> struct Geo {
 };
 
 // (second launch bound = minimum waves per SIMD: the 64-channel bf16 tiles sit one register above the three-workgroup limit)
-template <int TM, int TN, int KS, int S, bool INB, int NW, bool STAGED>
-__global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3 : 1) void conv_rows_bf16(RowsArgs p) {
+template <int TM, int TN, int KS, int S, bool INB, int NW, bool STAGED, bool DS = false>
+__global__ __launch_bounds__(64 * NW, DS ? 2 : ((TM == 2 && TN == 2 && INB && NW == 4) ? 3 : 1)) void conv_rows_bf16(RowsArgs p) {
+  static_assert(!DS || (KS == 3 && S == 2 && INB && STAGED), "the fused downsample branch rides on the stride-2 3x3 kernel");
   using G = Geo<TM, KS, S, NW>;
   constexpr int NT = 64 * NW;
   constexpr int BN = TN * 32;
@@ -551,6 +559,18 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // fused downsample branch: its own accumulators; one weight piece per thread and chunk ([BN rows][32 channels] of W2)
+  constexpr int NWD = DS ? (BN * 4 + NT - 1) / NT : 1;
+  f32x16 dacc[DS ? TM : 1][DS ? TN : 1];
+  u32x4 rwd[NWD];
+  if constexpr (DS) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dacc[i][j][e] = 0.f;
+  }
 
   for (int i = t; i < G::ROWS * BN * 2; i += NT) wst[i] = 0.f;  // (rows past the image stay zero; the loop's barriers order this)
   const int nchunk = p.Cin / CK;
@@ -558,6 +578,15 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
   for (int c = 0; c < nchunk; ++c) {
     CSTAMP(1 + 8 * c);
     store_patch(c * CK);  // (the barrier that ended the previous chunk's last stage made the patch free)
+    if constexpr (DS) {  // this chunk's slice of the downsample weights: requested now, staged behind the three filter rows
+#pragma unroll
+      for (int i = 0; i < NWD; ++i) {
+        const int u = t + NT * i, row = u >> 2;
+        const int n = min(n0 + row, p.Cout - 1);
+        rwd[i] = *reinterpret_cast<const u32x4*>(p.w2 + (long long)n * p.ldw2 + c * CK + (u & 3) * 8);
+        if (row >= BN || n0 + row >= p.Cout) rwd[i] = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
     CSTAMP(2 + 8 * c);
     const bool more = c + 1 < nchunk;
 #pragma unroll
@@ -628,6 +657,31 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
       CSTAMP(4 + 8 * c + 2 * kh);
       __syncthreads();
     }
+    if constexpr (DS) {
+      // The downsample branch: the 1x1 / stride-2 convolution samples input pixel (2y, 2x) = tap (kh, kw) = (1, 1) of the 3x3 / stride-2
+      // window around output (y, x), which is already in the patch.  One more stage per chunk on the weight buffer's first BN rows;
+      // same k order as the stand-alone 1x1 kernel (chunk, k-step): identical accumulators.
+#pragma unroll
+      for (int i = 0; i < NWD; ++i) {
+        const int u = t + NT * i, row = u >> 2;
+        if (row < BN) *reinterpret_cast<u32x4*>(&Ws[row * LDP + (u & 3) * 8]) = rwd[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < CK / 16; ++ks) {
+        bf16x8 a[TM], bb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pl + ((G::row_step() * i + 1) * G::RS + G::tap_col(1)) * LDP + ks * 16));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wl + (j * 32) * LDP + ks * 16));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) dacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], dacc[i][j], 0, 0, 0);
+      }
+      __syncthreads();  // (the next chunk's patch / first weight stage overwrite what these MFMAs read)
+    }
   }
   CSTAMP(120);
 
@@ -647,6 +701,19 @@ __global__ __launch_bounds__(64 * NW, (TM == 2 && TN == 2 && INB && NW == 4) ? 3
     int t2;
     asm volatile("v_mov_b32 %0, %1" : "=v"(t2) : "v"(threadIdx.x));
     write_tile_stats<G::ROWS, BN>(p, wst, img, ty * tiles_x + tx, n0, t2);
+  }
+  if constexpr (DS) {  // the branch's own output tensor and statistics, through the same epilogue
+    __syncthreads();  // (write_tile_stats has read the table the second epilogue overwrites)
+    RowsArgs p2 = p;
+    p2.out = p.out2; p2.bias = p.bias2; p2.out_part = p.out_part2;
+    epilogue_rows<TM, TN, TN == 3, STAGED>(dacc, p2, img, Ho, Wo, y0 + wm * TM, x0, n0, tiles_x, tx, lane, Ps + wm * stage_elems<TN>(), wst,
+                                           wm * TM);
+    if (p2.out_part) {
+      __syncthreads();
+      int t3;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(t3) : "v"(threadIdx.x));
+      write_tile_stats<G::ROWS, BN>(p2, wst, img, ty * tiles_x + tx, n0, t3);
+    }
   }
   CSTAMP(122);
 }
@@ -1091,6 +1158,33 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
   else LAUNCH(2, 1, 2, 4);
 #undef LAUNCH2
 #undef LAUNCH
+  return mvt_launch_status();
+}
+
+// The stride-2 3x3 convolution of a ResidualBlock together with the block's 1x1 / stride-2 downsample branch of the same input
+// (blocks.py:112-128) in ONE launch: the downsample is the centre tap of the 3x3 window with its own weights, so the input patch is
+// staged once, one launch, one InstanceNorm-finish and one full read of the block input fewer per block.
+__attribute__((visibility("hidden"))) int mvt_detail_conv3x3s2_down(const void* in, const unsigned short* w3, int ldw3, const float* b3,
+                                                                    const unsigned short* wd, int ldwd, const float* bd, void* out3,
+                                                                    void* outd, int n, int H, int W, int Cin, int Cout, int ldo,
+                                                                    float* part3, float* partd, hipStream_t stream) {
+  MVT_REQUIRE(in && w3 && wd && out3 && outd && n > 0 && Cin % CK == 0 && Cout % 32 == 0 && Cout % 8 == 0 && ldo % 8 == 0 && ldo >= Cout);
+  MVT_REQUIRE((long long)H * W * Cin < (1LL << 31) && (long long)Cout * ldw3 < (1LL << 31) && ldwd >= Cin && ldw3 >= 9 * Cin);
+  MVT_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out3 & 15) == 0 && ((uintptr_t)outd & 15) == 0 && ((uintptr_t)w3 & 15) == 0 &&
+              ((uintptr_t)wd & 15) == 0 && ldw3 % 8 == 0 && ldwd % 8 == 0 && (!part3) == (!partd));
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  RowsArgs a{};
+  a.in = (const float*)in; a.w = w3; a.bias = b3; a.out = (float*)out3; a.in_stats = nullptr; a.out_part = part3;
+  a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldw = ldw3; a.ldo = ldo;
+  a.slots = mvt_detail_conv_rows_slots(Ho, Wo, 4);
+  a.in_bf16 = 1; a.out_bf16 = 1;
+  a.w2 = wd; a.bias2 = bd; a.out2 = (float*)outd; a.out_part2 = partd; a.ldw2 = ldwd;
+  const bool n96 = Cout % 64 != 0 && Cout % 96 == 0;
+  const long long tiles = (long long)n * mvt_cdiv(Ho, 4) * mvt_cdiv(Wo, TC) * mvt_cdiv(Cout, n96 ? 96 : 64);
+  MVT_REQUIRE(tiles < (1LL << 31));
+  static_assert(4 * stage_elems<2>() <= Geo<1, 3, 2, 4>::NSLOT * LDP && 4 * stage_elems<3>() <= Geo<1, 3, 2, 4>::NSLOT * LDP, "staged epilogue");
+  if (n96) hipLaunchKernelGGL((conv_rows_bf16<1, 3, 3, 2, true, 4, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_rows_bf16<1, 2, 3, 2, true, 4, true, true>), dim3((unsigned)tiles), dim3(256), 0, stream, a);
   return mvt_launch_status();
 }
 

@@ -4,6 +4,7 @@
 // patch, the per-tile statistics reduction, the residual InstanceNorm pass, the one-launch concat -- on the caller's stream over a
 // caller-provided workspace.  bf16 mode, bf16 activations (the configuration bench.py measures).  56 launches per call.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -122,13 +123,27 @@ static int encoder_run(const mvt_encoder_weights* w, const float* x4, const void
                        void* zout) -> int {
     const int ho = (hh + 2 - 3) / stride + 1, wo = (ww + 2 - 3) / stride + 1;
     float *s1 = nullptr, *s2 = nullptr, *sd = nullptr;
-    ENC_TRY(conv(c1, xin, MVT_IO_IN_BF16, base + P.y, hh, ww, cin, cout, 3, stride, 1, cout, x_stats, &s1, MVT_IO_OUT_BF16));
+    static const bool no_fold = getenv("MVT_FOLD_DOWNSAMPLE") && atoi(getenv("MVT_FOLD_DOWNSAMPLE")) == 0;  // (A/B runs)
+    const bool fold = cd >= 0 && stride == 2 && !x_stats && cout % 32 == 0 && !no_fold;  // conv1 + downsample[0] read the same x: one launch
+    if (fold) {
+      const int slots = mvt_conv2d_stat_slots(hh, ww, cin, 3, 3, 2, 1, 0);
+      MVT_REQUIRE(slots > 0);
+      float* part_d = part + (long long)n * slots * cout * 2;  // (the partials buffer is sized for the stem: room for both)
+      ENC_TRY(mvt_conv3x3s2_down_bf16(xin, w->conv[c1].w, w->conv[c1].b, w->conv[cd].w, w->conv[cd].b, base + P.y, base + P.d, n, hh, ww, cin,
+                                      cout, cout, part, part_d, stream));
+      s1 = new_st();
+      ENC_TRY(mvt_instnorm_finish_slots(part, slots, s1, n, (long long)ho * wo, cout, stream));
+      sd = new_st();
+      ENC_TRY(mvt_instnorm_finish_slots(part_d, slots, sd, n, (long long)ho * wo, cout, stream));
+    } else {
+      ENC_TRY(conv(c1, xin, MVT_IO_IN_BF16, base + P.y, hh, ww, cin, cout, 3, stride, 1, cout, x_stats, &s1, MVT_IO_OUT_BF16));
+    }
     ENC_TRY(conv(c2, base + P.y, MVT_IO_IN_BF16, zout, ho, wo, cout, cout, 3, 1, 1, cout, s1, &s2, MVT_IO_OUT_BF16));
     const void* skip = xin;
     const float* skip_stats = x_stats;
     int flags = BF | (x_stats ? MVT_APPLY_SKIP_RELU : 0);
     if (cd >= 0) {
-      ENC_TRY(conv(cd, xin, MVT_IO_IN_BF16, base + P.d, hh, ww, cin, cout, 1, stride, 0, cout, nullptr, &sd, MVT_IO_OUT_BF16));
+      if (!fold) ENC_TRY(conv(cd, xin, MVT_IO_IN_BF16, base + P.d, hh, ww, cin, cout, 1, stride, 0, cout, nullptr, &sd, MVT_IO_OUT_BF16));
       skip = base + P.d;
       skip_stats = sd;
       flags = BF;

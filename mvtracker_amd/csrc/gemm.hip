@@ -848,6 +848,19 @@ extern "C" int mvt_conv2d_stat_slots(int H, int W, int Cin, int KH, int KW, int 
   return ((long long)Ho * Wo) % 256 == 0 ? Ho * Wo / 32 : 0;  // im2col tiles are <= 256 rows: they must not straddle images
 }
 
+int mvt_detail_conv3x3s2_down(const void* in, const unsigned short* w3, int ldw3, const float* b3, const unsigned short* wd, int ldwd,
+                              const float* bd, void* out3, void* outd, int n, int H, int W, int Cin, int Cout, int ldo, float* part3,
+                              float* partd, hipStream_t stream);
+extern "C" int mvt_conv3x3s2_down_bf16(const void* in, const unsigned short* w3, const float* b3, const unsigned short* wd, const float* bd,
+                                       void* out3, void* outd, int n, int H, int W, int Cin, int Cout, int ldo, float* part3,
+                                       float* partd, void* stream) {
+  MVT_REQUIRE(in && w3 && wd && out3 && outd && n > 0 && H > 1 && W > 1 && H < 16384 && W < 16384 && Cin > 0 && Cout > 0);
+  MVT_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && (long long)n * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) < (1LL << 31));
+  // (weight rows as mvt_conv2d_bf16 takes them: [Cout][round_up(K, 64)], zero padded)
+  return mvt_detail_conv3x3s2_down(in, w3, (9 * Cin + BKB - 1) / BKB * BKB, b3, wd, (Cin + BKB - 1) / BKB * BKB, bd, out3, outd, n, H, W, Cin,
+                                   Cout, ldo, part3, partd, mvt_stream(stream));
+}
+
 extern "C" int mvt_conv2d_bf16(const void* in, const unsigned short* wt_hi, const unsigned short* wt_lo, const float* bias,
                                void* out, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int ldo,
                                int act, int io_flags, const float* in_stats, float* out_partial, void* stream) {

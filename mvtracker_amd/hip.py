@@ -35,6 +35,7 @@ SIGNATURES = {
     "mvt_gemm_bf16": [P, I, P, P, I, P, P, I, P, I, I, I, I, I, I, P],
     "mvt_conv2d_stat_slots": [I, I, I, I, I, I, I, I],
     "mvt_conv2d_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P],
+    "mvt_conv3x3s2_down_bf16": [P, P, P, P, P, P, P, I, I, I, I, I, I, P, P, P],
     "mvt_instnorm_finish_slots": [P, I, P, I, LL, I, P],
     "mvt_ln_gemm_bf16": [P, I, P, P, F, P, P, I, P, P, I, P, I, I, I, I, I, P],
     "mvt_pack_frag_bf16": [P, I, I, I, P, P],
@@ -215,6 +216,13 @@ def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, 
     3x3 layers then run on the 64-channel row tiles instead of one 512-thread workgroup per CU; identical results)."""
     _call("mvt_conv2d_bf16", _ptr(x), _ptr(wt_hi), _ptr(wt_lo), _ptr(bias), _ptr(out), n, H, W, Cin, Cout, KH, KW, stride, pad,
           ldo, act, _io(x, out) | (IO_SHORT_WG if short_wg else 0), _ptr(in_stats), _ptr(out_partial), _stream())
+
+
+def conv3x3s2_down_bf16(x, w3, b3, wd, bd, out3, outd, n, H, W, Cin, Cout, ldo, part3=None, partd=None):
+    """conv1 (3x3 / stride 2) and downsample[0] (1x1 / stride 2) of a strided ResidualBlock in one launch (bf16 tensors)."""
+    assert x.dtype == torch.bfloat16 and out3.dtype == torch.bfloat16 and outd.dtype == torch.bfloat16
+    _call("mvt_conv3x3s2_down_bf16", _ptr(x), _ptr(w3), _ptr(b3), _ptr(wd), _ptr(bd), _ptr(out3), _ptr(outd), n, H, W, Cin, Cout, ldo,
+          _ptr(part3), _ptr(partd), _stream())
 
 
 def instnorm_finish_slots(partial, slots, mean_rstd, n, HW, Cc):

@@ -175,6 +175,7 @@ class MVTracker(nn.Module):
         self.fuse_input = os.environ.get("MVT_FUSE_INPUT", "1") != "0"  # input transform + virtual tokens + first q|k|v in one launch
         self.fuse_head = os.environ.get("MVT_FUSE_HEAD", "1") != "0"  # flow head + track / feature update in one kernel
         self.fuse_norm = True  # InstanceNorm statistics from the conv epilogue + normalise-on-load (bf16 / bf16x3 convs)
+        self.fold_downsample = os.environ.get("MVT_FOLD_DOWNSAMPLE", "1") != "0"  # strided blocks: conv1 + downsample[0] in one launch
         self.fuse_ln = False
         d = self.updateformer_input_dim
         self._time_embed_host = self._make_time_embed(self.S, d)
@@ -491,13 +492,30 @@ class MVTracker(nn.Module):
         materialised (the stem): conv1 normalises while it loads and the skip connection is normalised in the final pass."""
         fuse_in = self.fuse_norm and isinstance(pk[p + ".conv2"][0], tuple) and cout % 32 == 0
         assert x_stats is None or (stride == 1 and (p + ".downsample.0") not in pk)
-        y, Ho, Wo, st1 = self._conv(pk, p + ".conv1", x, n, H, W, cin, cout, 3, stride, 1, stats=True, in_stats=x_stats)
+        d = dst = None
+        fold = (fuse_in and stride == 2 and (p + ".downsample.0") in pk and x.dtype == torch.bfloat16 and pk[p + ".conv1"][0][1] is None
+                and self.fold_downsample)
+        if fold:
+            # conv1 (3x3 / stride 2) and downsample[0] (1x1 / stride 2) read the same x: one launch (mvt_conv3x3s2_down_bf16)
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            y = torch.empty(n, Ho, Wo, cout, device=x.device, dtype=torch.bfloat16)
+            d = torch.empty(n, Ho, Wo, cout, device=x.device, dtype=torch.bfloat16)
+            slots = hip.conv2d_stat_slots(H, W, cin, 3, 3, 2, 1, False)
+            part = torch.empty(2, n * slots * cout * 2, device=x.device)
+            (w1, b1), (wd, bd) = pk[p + ".conv1"], pk[p + ".downsample.0"]
+            hip.conv3x3s2_down_bf16(x, w1[0], b1, wd[0], bd, y, d, n, H, W, cin, cout, cout, part[0], part[1])
+            st1, dst = torch.empty(n, cout, 2, device=x.device), torch.empty(n, cout, 2, device=x.device)
+            hip.instnorm_finish_slots(part[0], slots, st1, n, Ho * Wo, cout)
+            hip.instnorm_finish_slots(part[1], slots, dst, n, Ho * Wo, cout)
+        else:
+            y, Ho, Wo, st1 = self._conv(pk, p + ".conv1", x, n, H, W, cin, cout, 3, stride, 1, stats=True, in_stats=x_stats)
         if not fuse_in:  # otherwise conv2 normalises while it loads its patch
             self._inorm(y, n, Ho * Wo, cout, st=st1)
         y2, _, _, st2 = self._conv(pk, p + ".conv2", y, n, Ho, Wo, cout, cout, 3, 1, 1, in_stats=st1 if fuse_in else None,
                                    stats=True)
         if (p + ".downsample.0") in pk:
-            d, _, _, dst = self._conv(pk, p + ".downsample.0", x, n, H, W, cin, cout, 1, stride, 0, stats=True)
+            if d is None:
+                d, _, _, dst = self._conv(pk, p + ".downsample.0", x, n, H, W, cin, cout, 1, stride, 0, stats=True)
             self._inorm(y2, n, Ho * Wo, cout, skip=d, skip_stats=dst, st=st2)
         else:
             self._inorm(y2, n, Ho * Wo, cout, skip=x, skip_stats=x_stats, skip_relu=x_stats is not None, st=st2)

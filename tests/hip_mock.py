@@ -129,6 +129,20 @@ def conv2d_stat_slots(H, W, Cin, KH, KW, stride, pad, split=False):
     return Ho * Wo // 32 if (Ho * Wo) % 256 == 0 else 0
 
 
+def conv3x3s2_down_bf16(x, w3, b3, wd, bd, out3, outd, n, H, W, Cin, Cout, ldo, part3=None, partd=None):
+    """conv1 + downsample[0] of a strided ResidualBlock: the two convolutions of the same input (mock: two calls)."""
+    conv2d_bf16(x, w3, None, b3, out3, n, H, W, Cin, Cout, 3, 3, 2, 1, ldo, out_partial=part3)
+    conv2d_bf16(x, wd, None, bd, outd, n, H, W, Cin, Cout, 1, 1, 2, 0, ldo, out_partial=None)
+    if partd is not None:  # (the fused kernel cuts BOTH outputs into the 3x3 kernel's slots; the mock: whole-image sum in slot 0)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        slots = conv2d_stat_slots(H, W, Cin, 3, 3, 2, 1)
+        y = torch.as_strided(outd, (n, Ho * Wo, Cout), (Ho * Wo * ldo, ldo, 1)).float()
+        pp = partd.reshape(-1)[:n * slots * Cout * 2].reshape(n, slots, Cout, 2)
+        pp.zero_()
+        pp[:, 0, :, 0] = y.sum(1)
+        pp[:, 0, :, 1] = (y * y).sum(1)
+
+
 def conv2d_bf16(x, wt_hi, wt_lo, bias, out, n, H, W, Cin, Cout, KH, KW, stride, pad, ldo, act=0, in_stats=None, out_partial=None, short_wg=False):
     K = KH * 32 if Cin == 4 else KH * KW * Cin
     ld = (K + 63) // 64 * 64

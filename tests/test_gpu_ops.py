@@ -252,6 +252,41 @@ def test_conv_big_tile_bit_identical(hip, cfg, monkeypatch):
     assert (ps[..., 0] - ref.sum((1, 2))).abs().max() / ref.sum((1, 2)).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 96, 64, 96), (1, 90, 160, 96, 128), (3, 33, 41, 128, 128), (2, 32, 32, 64, 64)])
+def test_conv3x3s2_with_downsample_branch(hip, cfg):
+    """mvt_conv3x3s2_down_bf16: conv1 (3x3 / stride 2) and downsample[0] (1x1 / stride 2) of a strided ResidualBlock
+    (spatracker/blocks.py:84-128) in one launch -- the downsample as the centre tap of the 3x3 window -- against the two separate
+    launches: both output tensors identical, bit for bit; conv1's statistics partials identical; the downsample's statistics (cut into
+    4-row instead of 8-row tiles: another fixed summation order) equal after the slot reduction to fp32 rounding.  Odd sizes (a
+    ragged last tile in both directions), 64- and 96-channel tiles."""
+    n, H, W, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + 11)
+    x = G((torch.randn(n, H, W, Cin, generator=g) * 1.5 + 0.3).to(torch.bfloat16))
+    w3 = torch.randn(Cout, 3, 3, Cin, generator=g) / math.sqrt(Cin * 9)
+    wd = torch.randn(Cout, 1, 1, Cin, generator=g) / math.sqrt(Cin)
+    b3, bd = G(torch.randn(Cout, generator=g)), G(torch.randn(Cout, generator=g))
+    h3, _ = split(hip, G(pad_w(w3.reshape(Cout, -1))), False)
+    hd, _ = split(hip, G(pad_w(wd.reshape(Cout, -1))), False)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    s3 = hip.conv2d_stat_slots(H, W, Cin, 3, 3, 2, 1, False)
+    sd = hip.conv2d_stat_slots(H, W, Cin, 1, 1, 2, 0, False)
+    o3 = torch.full((n, Ho, Wo, Cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+    od, f3, fd = o3.clone(), o3.clone(), o3.clone()
+    p3 = torch.full((n * s3 * Cout * 2,), float("nan"), device=DEV)
+    pd = torch.full((n * sd * Cout * 2,), float("nan"), device=DEV)
+    q3, qd = p3.clone(), torch.full((n * s3 * Cout * 2,), float("nan"), device=DEV)
+    hip.conv2d_bf16(x, h3, None, b3, o3, n, H, W, Cin, Cout, 3, 3, 2, 1, Cout, out_partial=p3)
+    hip.conv2d_bf16(x, hd, None, bd, od, n, H, W, Cin, Cout, 1, 1, 2, 0, Cout, out_partial=pd)
+    hip.conv3x3s2_down_bf16(x, h3, b3, hd, bd, f3, fd, n, H, W, Cin, Cout, Cout, q3, qd)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(f3.float()).all()) and bool(torch.isfinite(fd.float()).all())
+    assert torch.equal(f3, o3) and torch.equal(fd, od)
+    assert torch.equal(q3, p3)
+    a = pd.reshape(n, sd, Cout, 2).double().sum(1)
+    b = qd.reshape(n, s3, Cout, 2).double().sum(1)
+    assert bool(torch.isfinite(qd).all()) and ((a - b).abs().max() / a.abs().max()).item() < 1e-6
+
+
 def test_encoder_elementwise_bf16_tensors(hip):
     g = torch.Generator().manual_seed(77)
     n, Hh, Ww, C = 2, 12, 20, 96

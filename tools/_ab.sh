@@ -1,11 +1,7 @@
-python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "conv or encoder" 2>&1 | tail -2
-for rep in 1 2; do
-for lib in "" nopack; do
-  if [ -n "$lib" ]; then export MVT_LIB=mvtracker_amd/lib/libmvtracker_hip_$lib.so; else unset MVT_LIB; fi
-  echo "== ${lib:-new(4 waves 1x1)}"
-  python tools/prof_conv.py 24 128 128 256 128 1 1 0 1
-  python tools/prof_conv.py 24 256 256 64 96 1 2 0 1
-  python tools/prof_conv.py 24 128 128 96 128 1 2 0 1
-  python tools/prof_conv.py 24 64 64 128 128 1 2 0 1
-done
-done
+python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "conv or encoder" 2>&1 | tail -3
+python -m pytest tests/test_gpu_e2e.py -x -q -m gpu -k "encoder or golden" 2>&1 | tail -3
+run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-corr-calibration | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['ms_per_step'],3), round(d['roofline_mfma']['encoder']['frac'],4), 'corr', round(r['frac'],3))"; }
+run MVT_FOLD_DOWNSAMPLE=1
+run MVT_FOLD_DOWNSAMPLE=0
+run MVT_FOLD_DOWNSAMPLE=1
+run MVT_FOLD_DOWNSAMPLE=0

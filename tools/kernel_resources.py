@@ -24,5 +24,5 @@ for line in r.stderr.splitlines():
 for name, d in rows.items():
     if filt in name:
         short = name.replace("(anonymous namespace)::", "").split("(")[0]
-        print(f"{short:70s} VGPR {d.get('VGPRs', '?'):>4s} spill {d.get('VGPRs Spill', '?'):>3s} scratch {d.get('ScratchSize', '?'):>4s} "
+        print(f"{short:70s} VGPR {d.get('VGPRs', '?'):>4s} AGPR {d.get('AGPRs', '0'):>3s} spill {d.get('VGPRs Spill', '?'):>3s} scratch {d.get('ScratchSize', '?'):>4s} "
               f"LDS {d.get('LDS Size', '?'):>7s} waves/SIMD {d.get('Occupancy', '?')}")
