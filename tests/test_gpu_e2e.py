@@ -794,6 +794,40 @@ def test_updater_fused_attention_matches_separate_launches(model, n):
         assert rel < 1.1e-2 and mean < 9e-3, (f, rel, mean)  # 1.5 x the measured 7e-3 / 6e-3
 
 
+@pytest.mark.parametrize("S,n", [(7, 50), (8, 333), (16, 37), (32, 21), (12, 341)])
+def test_time_attention_block_diagonal_other_window_lengths(S, n, W):
+    """The in-kernel time attention (block_fused_bf16 ATT 1: the tracks of a 64-row tile as ONE block-diagonal 64 x 64 unit per head,
+    a query sees the keys of its own track; single-pass softmax) at other window lengths -- 9 / 8 / 5 / 4 / 2 whole tracks per tile,
+    ragged last tiles, tiles that straddle the point / virtual-token boundary -- against (a) the separate attention launches of the
+    same updater (attention_mfma_kernel, itself checked against fp64 torch in test_gpu_ops.py) at the bf16-rounding bar and (b) the
+    oracle's EfficientUpdateFormer in fp32 (cotracker2/blocks.py:455-494) at the bf16 stage bar: a masking or indexing slip in the
+    block-diagonal path would show as an O(1) error on the affected rows in both."""
+    from mvtracker_amd.tracker import MVTracker
+    cfg = O.TrackerConfig(sliding_window_len=S)
+    m = MVTracker(hidden_size=256, sliding_window_len=S).eval()
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV)
+    m.precision = "bf16"
+    x = torch.randn(1, n, S, m.updateformer_input_dim, generator=torch.Generator().manual_seed(S * 1000 + n))
+    outs = {}
+    for f in (0, 1, 55):
+        m.fuse_attention = f
+        assert "updater_struct" in m._pack(torch.device(DEV))
+        outs[f] = m.update_former(x.to(DEV)).clone()
+    torch.cuda.synchronize()
+    for f in (1, 55):
+        rel = ((outs[f] - outs[0]).abs().max() / outs[0].abs().max()).item()
+        mean = ((outs[f] - outs[0]).abs().mean() / outs[0].abs().mean()).item()
+        print(f"S={S} n={n} fuse_attention={f}: max {rel:.2e} mean {mean:.2e}")
+        assert rel < 1.1e-2 and mean < 9e-3, (f, rel, mean)
+    with torch.no_grad():
+        ref = O.update_former(O.make_weights(cfg, 0), x, cfg).numpy()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ac = O.update_former(O.make_weights(cfg, 0), x, cfg).float().numpy()
+    _bf16_stage_check(f"updater S={S} n={n}", outs[55].cpu().numpy(), ref, ac, (2.5e-2, 2e-2))
+
+
 def test_single_point_streams_match_sequential(model):
     """single_point mode spreads the independent per-query forwards over several HIP streams: results identical to one stream,
     bit for bit (fp32 and bf16 -- per-stream scratch, no shared mutable state between the forwards)."""
