@@ -1,7 +1,10 @@
-python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "conv or encoder" 2>&1 | tail -3
-python -m pytest tests/test_gpu_e2e.py -x -q -m gpu -k "encoder or golden" 2>&1 | tail -3
-run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-corr-calibration | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['ms_per_step'],3), round(d['roofline_mfma']['encoder']['frac'],4), 'corr', round(r['frac'],3))"; }
-run MVT_FOLD_DOWNSAMPLE=1
-run MVT_FOLD_DOWNSAMPLE=0
-run MVT_FOLD_DOWNSAMPLE=1
-run MVT_FOLD_DOWNSAMPLE=0
+timeout -k 10 200 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "c64_persistent" 2>&1 | tail -3
+for rep in 1 2; do
+for on in 1 0; do
+  export MVT_CONV_C64=$on; echo "== MVT_CONV_C64=$on"
+  timeout -k 10 60 python tools/prof_conv.py 24 256 256 64 64 3 1 1 1
+  timeout -k 10 60 python tools/prof_conv.py 24 256 256 64 64 3 1 1 1 0
+done
+done
+unset MVT_CONV_C64
+STAMP_RAW=1 STAMP_NORM=1 MVT_LIB=mvtracker_amd/lib/libmvtracker_hip_stamps.so timeout -k 5 100 python tools/stamp_conv.py 24 256 256 64 64 > gpurun_out/r4_stamp_c64b.txt 2>&1

@@ -45,7 +45,9 @@ buf = np.zeros(2 * NWV * 128, dtype=np.uint64)
 assert lib.mvt_debug_read_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 buf = buf.reshape(2, NWV, 128).astype(np.int64)
 names = {0: "start", 120: "loop end", 121: "epilogue", 122: "end"}
-for c in range(14):
+if os.environ.get("STAMP_RAW"):
+    names = {}
+for c in range(0 if os.environ.get('STAMP_RAW') else 14):
     names.update({1 + 8 * c: f"c{c} top", 2 + 8 * c: f"c{c} patch st"})
     for kh in range(3):
         names.update({3 + 8 * c + 2 * kh: f"c{c} kh{kh} bar", 4 + 8 * c + 2 * kh: f"c{c} kh{kh} mfma"})
