@@ -1068,242 +1068,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_big_bf16(RowsArgs p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Round 4: the 64 -> 64 channel 3x3 / stride-1 convolutions (BasicEncoder.layer1, four per image chunk at H/2: 29 % of the
-// encoder's convolution time, spatracker/blocks.py:84-128) as a PERSISTENT kernel: one 512-thread workgroup per CU walks a run
-// of 8 x 32 pixel tiles.
-//   * ALL 9 x 64 x 64 weights (73.7 KB) are DMA'd into LDS once per workgroup -- the row tiles stream them from L2 for every tile;
-//   * the raw input patch of a tile (10 x 34 pixels x 64 channels = 43.5 KB) arrives by LDS-DMA into one of two buffers, requested a
-//     whole tile ahead (while the previous tile's MFMAs run): the memory round trip that starts every row tile's serial chain, and
-//     with it the shortage of requests in flight (three chains per CU, ~4 MB outstanding chip-wide against the ~12 MB HBM needs), is
-//     gone; the producer's InstanceNorm + ReLU (and the zero padding, which applies AFTER the normalisation) is applied IN PLACE in
-//     LDS by all eight waves -- the packed arithmetic of the row tiles' loader, bit-identical;
-//   * 128-B pixel slots (all 64 channels) with the 16-B pieces XOR-swizzled by (column >> 1) & 7, weight rows of 64 B swizzled by
-//     (row >> 2) & 3 -- on the DMA's source address and on the read address: conflict-free ds_read_b128 without padding;
-//   * a wave owns one tile row x 64 channels (two accumulators); no barrier and no global access inside a tile's 72 MFMAs per
-//     wave, fragments read one tap ahead;
-//   * epilogue and per-tile statistics are the row tiles' (epilogue_rows), staged in the tile's own -- by then dead -- patch buffer.
-// Three barriers per tile.  Same accumulation order (chunk, kh, kw, k-step) as conv_rows_bf16: bit-identical outputs and statistics
-// (tests/test_gpu_ops.py::test_conv_c64_persistent_bit_identical).  Like conv3x3_big_bf16 it owns every CU for its whole run:
-// not launched under MVT_IO_SHORT_WG.
-constexpr int C6_PC = TC + 2;                         // 34 patch columns
-constexpr int C6_PSLOTS = (TR + 2) * C6_PC;           // 340 pixel slots of 128 B
-constexpr int C6_PROW = C6_PC * 128;                  // 4 352 B per patch row
-constexpr int C6_PINSTR = (C6_PSLOTS * 128 + 1023) / 1024;  // 43 DMA wave-instructions per tile
-constexpr int C6_PBYTES = C6_PINSTR * 1024;           // 44 032 B per patch buffer
-constexpr int C6_WBYTES = 18 * 64 * 64;               // 73 728 B: [chunk 2][tap 9][cout 64] rows of 32 channels
-constexpr int C6_SST = 2 * 64 * 4;                    // (-mean | rstd) of the 64 input channels
-constexpr int C6_LDS = C6_WBYTES + 2 * C6_PBYTES + C6_SST;  // 162 304 B of 163 840
-constexpr int C6_STAGE = 8 * stage_elems<2>() * 2;    // 36 864 B of staging tiles, then the statistics table (4 KB), in a patch buffer
-static_assert(C6_LDS <= 160 * 1024, "one workgroup per CU");
-static_assert(C6_STAGE + TR * 64 * 2 * 4 <= C6_PBYTES, "staging tiles + statistics table fit a patch buffer");
-
-__global__ __launch_bounds__(512, 2) void conv3x3_c64_bf16(RowsArgs p, int tiles_per_wg, long long total_tiles) {
-  constexpr int TM = 1, TN = 2;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[C6_LDS];  // (ONE LDS object: weights | patch x2 | statistics)
-  unsigned char* const Wb = lds;
-  unsigned char* const Pb = lds + C6_WBYTES;
-  float* const Sn = reinterpret_cast<float*>(lds + C6_WBYTES + 2 * C6_PBYTES);  // [0, 64): -mean, [64, 128): rstd
-
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int Ho = p.H, Wo = p.W;
-  const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + TR - 1) / TR;
-  long long tile;
-  {  // XCD-aware: every XCD owns a contiguous run of workgroups, every workgroup a contiguous run of tiles
-    const unsigned nwg = gridDim.x, q = nwg / 8, rr = nwg % 8, xcd = blockIdx.x % 8;
-    tile = (long long)((xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + blockIdx.x / 8) * tiles_per_wg;
-  }
-  const long long tile_end = tile + tiles_per_wg < total_tiles ? tile + tiles_per_wg : total_tiles;
-  if (tile >= tile_end) return;  // (workgroup-uniform)
-  const unsigned char* const zero = reinterpret_cast<const unsigned char*>(mvt_conv_zero_page);
-
-  // ---- weights: instruction k = wave + 8 i (i < 9) fills rows 16 k .. 16 k + 15; row R = (chunk * 9 + tap) * 64 + cout, stored piece
-  // (lane & 3) holds channel piece (lane & 3) ^ ((R >> 2) & 3) of the chunk
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int R = (wave + 8 * i) * 16 + (lane >> 2);
-    const int q = (lane & 3) ^ ((R >> 2) & 3);
-    const int n = R & 63, ct = R >> 6, c = ct / 9, tap = ct - 9 * c;
-    dma16(reinterpret_cast<const unsigned char*>(p.w) + ((long long)n * p.ldw + tap * 64 + c * CK + q * 8) * 2, Wb + (wave + 8 * i) * 1024);
-  }
-  // ---- patch of a tile: instruction k = wave + 8 i (k < 43) fills pieces 64 k .. 64 k + 63 of a buffer; piece P = slot P >> 3 (patch
-  // row py, column px), stored piece P & 7 holds channel piece (P & 7) ^ ((px >> 1) & 7)
-  int tx, ty, y0, x0;
-  long long img;
-  auto decode = [&](long long b) {
-    tx = (int)(b % tiles_x); b /= tiles_x;
-    ty = (int)(b % tiles_y);
-    img = b / tiles_y;
-    y0 = ty * TR; x0 = tx * TC;
-  };
-  // (the lane's patch coordinates and byte offset relative to the tile's first patch pixel do not depend on the tile: computed once)
-  int dpos[6], drel[6];  // (py << 8 | px), or -1 behind the last slot; ((py * W + px) * 64 + q * 8) * 2
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int P = (wave + 8 * i) * 64 + lane;
-    const int slot = P >> 3, py = slot / C6_PC, px = slot - py * C6_PC;
-    const int q = (P & 7) ^ ((px >> 1) & 7);
-    dpos[i] = slot < C6_PSLOTS ? (py << 8 | px) : -1;
-    drel[i] = ((py * p.W + px) * 64 + q * 8) * 2;
-  }
-  auto dma_patch = [&](int buf) {  // the tile in (img, y0, x0)
-    const unsigned char* org = reinterpret_cast<const unsigned char*>(p.in) + (img * (long long)p.H * p.W + (long long)(y0 - 1) * p.W + (x0 - 1)) * 128;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int k = wave + 8 * i;
-      if (k < C6_PINSTR) {  // (wave-uniform)
-        const int gy = y0 - 1 + (dpos[i] >> 8), gx = x0 - 1 + (dpos[i] & 255);
-        const bool ok = dpos[i] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        dma16(ok ? org + drel[i] : zero, Pb + buf * C6_PBYTES + k * 1024);
-      }
-    }
-  };
-  auto load_stats = [&]() {  // (-mean, rstd) of the input channels of image `img`
-    if (t < 128) {
-      const float v = p.in_stats[img * 128 + (t & 63) * 2 + (t >> 6)];
-      Sn[t] = t < 64 ? -v : v;
-    }
-  };
-  decode(tile);
-  dma_patch(0);
-  long long st_img = -1;
-  if (p.in_stats) {
-    load_stats();
-    st_img = img;
-  }
-
-  // ---- fragment read bases.  A: lane (r, h), tap kw, chunk c, k-step ks reads slot (row, kw + r), stored piece
-  // (4 c + 2 ks + h) ^ (((kw + r) >> 1) & 7); B: row (c * 9 + tap) * 64 + 32 j + r, stored piece (2 ks + h) ^ ((r >> 2) & 3)
-  int pa[3][2][2], wl[2][2];
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        pa[kw][c][ks] = (wave * C6_PC + kw + r) * 128 + (((4 * c + 2 * ks + h) ^ (((kw + r) >> 1) & 7)) << 4);
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) wl[c][ks] = (c * 9 * 64 + r) * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4);
-
-  // the in-place normalisation: a thread owns ONE channel octet (t & 7) and walks pixel slots (t >> 3) + 64 i; the octet's stored
-  // position inside a slot follows the slot's swizzle (tile-independent: computed once)
-  constexpr int NP = (C6_PSLOTS + 63) / 64;
-  int tpos[NP], toff[NP];  // (py << 8 | px) or -1; byte offset of the piece in a patch buffer
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int slot = (t >> 3) + 64 * i, py = slot / C6_PC, px = slot - py * C6_PC;
-    tpos[i] = slot < C6_PSLOTS ? (py << 8 | px) : -1;
-    toff[i] = slot * 128 + (((t & 7) ^ ((px >> 1) & 7)) << 4);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // weights, the first patch and the statistics are in LDS
-#ifdef MVT_C64_STAGGER
-  // experiment: every workgroup runs the same phases from the same start -- the chip loads, computes and stores in lockstep bursts;
-  // offset the workgroups against each other
-  for (unsigned i = 0; i < (blockIdx.x / 8 % 4) * MVT_C64_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
-#endif
-
-  for (int it = 0; tile + it < tile_end; ++it) {
-    const int buf = it & 1;
-    unsigned char* const Pc = Pb + buf * C6_PBYTES;
-    const int e_tx = tx, e_ty = ty, e_y0 = y0, e_x0 = x0;
-    const long long e_img = img;
-    // ---- 1. the producer's InstanceNorm + ReLU in place, zero padding behind it (mvtracker's convs pad the NORMALISED tensor)
-    if (p.in_stats) {
-      // (all pieces are read before the first is rewritten; the octet's statistics once per tile)
-      const int q = t & 7;
-      const f32x4 nm0 = *reinterpret_cast<const f32x4*>(Sn + q * 8), nm1 = *reinterpret_cast<const f32x4*>(Sn + q * 8 + 4);
-      const f32x4 rs0 = *reinterpret_cast<const f32x4*>(Sn + 64 + q * 8), rs1 = *reinterpret_cast<const f32x4*>(Sn + 64 + q * 8 + 4);
-      u32x4 w[NP];
-#pragma unroll
-      for (int i = 0; i < NP; ++i)
-        if (tpos[i] >= 0) w[i] = *reinterpret_cast<const u32x4*>(Pc + toff[i]);
-      auto pair = [](unsigned ww, float nm0_, float nm1_, float r0, float r1) -> unsigned {
-        f32x2 v = (f32x2){__uint_as_float(ww << 16), __uint_as_float(ww & 0xFFFF0000u)};
-        v = (v + (f32x2){nm0_, nm1_}) * (f32x2){r0, r1};
-        s16x2 qq = __builtin_bit_cast(s16x2, __builtin_convertvector(v, bf16x2));
-        qq = __builtin_elementwise_max(qq, (s16x2){0, 0});
-        return __builtin_bit_cast(unsigned, qq);
-      };
-#pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        if (tpos[i] < 0) continue;
-        u32x4 o = (u32x4){pair(w[i][0], nm0[0], nm0[1], rs0[0], rs0[1]), pair(w[i][1], nm0[2], nm0[3], rs0[2], rs0[3]),
-                          pair(w[i][2], nm1[0], nm1[1], rs1[0], rs1[1]), pair(w[i][3], nm1[2], nm1[3], rs1[2], rs1[3])};
-        const int gy = e_y0 - 1 + (tpos[i] >> 8), gx = e_x0 - 1 + (tpos[i] & 255);
-        if (!((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)) o = (u32x4){0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(Pc + toff[i]) = o;
-      }
-    }
-    if (it < 14) CSTAMP(1 + 8 * it);
-    __syncthreads();  // the patch is final; every wave is done with the previous tile's staging tiles and statistics table
-    if (it < 14) CSTAMP(2 + 8 * it);
-    // ---- 2. the next tile's patch is requested now and lands under this tile's MFMAs
-    const bool have_next = tile + it + 1 < tile_end;
-    if (have_next) {
-      decode(tile + it + 1);
-      dma_patch(buf ^ 1);
-    }
-    if (it < 14) CSTAMP(3 + 8 * it);
-    // ---- 3. 2 chunks x 9 taps x 2 k-steps: fragments of tap g + 1 are read while the four MFMAs of tap g issue
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
-    {
-      bf16x8 a[2][2], bb[2][2][TN];  // [set][ks]
-      auto read_tap = [&](int set, int g) {  // g = chunk * 9 + kh * 3 + kw
-        const int c = g / 9, tap = g - 9 * c, kh = tap / 3, kw = tap - 3 * kh;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          a[set][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Pc + pa[kw][c][ks] + kh * C6_PROW));
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            bb[set][ks][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wb + wl[c][ks] + (tap * 64 + j * 32) * 64));
-        }
-      };
-      read_tap(0, 0);
-#pragma unroll
-      for (int g = 0; g < 18; ++g) {
-        if (g + 1 < 18) read_tap((g + 1) & 1, g + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][ks], bb[g & 1][ks][j], acc[0][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (it < 14) CSTAMP(4 + 8 * it);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's patch has landed (this wave's part; the barrier makes it everyone's)
-    if (it < 14) CSTAMP(5 + 8 * it);
-    __syncthreads();  // ... and every wave is done reading this tile's patch: it becomes the staging area
-    if (it < 14) CSTAMP(6 + 8 * it);
-    // ---- 4. epilogue (bias, bf16 rows, per-row statistics) through this wave's staging tile
-    float* const wst = reinterpret_cast<float*>(Pc + C6_STAGE);
-    for (int i = lane; i < 128; i += 64) wst[wave * 128 + i] = 0.f;  // this wave's tile row (stays zero past the image)
-    epilogue_rows<TM, TN, false, true, 64>(acc, p, e_img, Ho, Wo, e_y0 + wave, e_x0, 0, tiles_x, e_tx, lane,
-                                           reinterpret_cast<unsigned short*>(Pc) + wave * stage_elems<TN>(), wst, wave);
-    if (it < 14) CSTAMP(7 + 8 * it);
-    if (p.out_part) {
-      __syncthreads();
-      write_tile_stats<TR, 64>(p, wst, e_img, e_ty * tiles_x + e_tx, 0, t);
-    }
-    if (it < 14) CSTAMP(8 + 8 * it);
-    if (have_next && p.in_stats && img != st_img) {  // (a run that crosses into the next image: its statistics)
-      __syncthreads();
-      load_stats();
-      st_img = img;
-      __syncthreads();
-    }
-  }
-}
-
 }  // namespace
 
 #ifdef MVT_STAMPS
@@ -1384,19 +1148,6 @@ __attribute__((visibility("hidden"))) int mvt_detail_conv_rows(const void* in, c
       const long long tiles = (long long)n * mvt_cdiv(Ho, TR) * mvt_cdiv(Wo, TC) * (Cout / BG_BN);
       MVT_REQUIRE(tiles < (1LL << 31));
       hipLaunchKernelGGL(conv3x3_big_bf16, dim3((unsigned)tiles), dim3(512), 0, stream, a);
-      return mvt_launch_status();
-    }
-  }
-  // the 64 -> 64 channel layers (layer1): persistent, weights resident in LDS, patches by LDS-DMA a tile ahead (conv3x3_c64_bf16).
-  // MVT_CONV_C64=0 keeps the row tiles (read per call: A/B runs, tests)
-  if (ksize == 3 && stride == 1 && Cin == 64 && Cout == 64 && !(io_flags & MVT_IO_SHORT_WG) && a.in_bf16 && st_ok && ldw % 8 == 0 &&
-      ((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0 && (long long)H * W * 64 * 2 < (1LL << 31)) {
-    const char* e = getenv("MVT_CONV_C64");
-    if (!e || atoi(e) != 0) {
-      const long long tiles = (long long)n * mvt_cdiv(Ho, TR) * mvt_cdiv(Wo, TC);
-      const long long per = mvt_cdiv(tiles, 256);  // one workgroup per CU
-      MVT_REQUIRE(tiles < (1LL << 31));
-      hipLaunchKernelGGL(conv3x3_c64_bf16, dim3((unsigned)mvt_cdiv(tiles, per)), dim3(512), 0, stream, a, (int)per, tiles);
       return mvt_launch_status();
     }
   }

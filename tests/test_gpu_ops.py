@@ -252,42 +252,6 @@ def test_conv_big_tile_bit_identical(hip, cfg, monkeypatch):
     assert (ps[..., 0] - ref.sum((1, 2))).abs().max() / ref.sum((1, 2)).abs().max() < 1e-4
 
 
-@pytest.mark.parametrize("cfg", [(2, 64, 96, True), (3, 33, 41, True), (1, 90, 160, False), (2, 8, 32, True), (5, 128, 128, True), (300, 8, 32, False)])
-def test_conv_c64_persistent_bit_identical(hip, cfg, monkeypatch):
-    """conv3x3_c64_bf16 (persistent: one 512-thread workgroup per CU walks a run of 8 x 32 tiles; all 64 -> 64 weights resident in LDS,
-    raw patches by LDS-DMA a tile ahead, the producer's InstanceNorm + ReLU and the zero padding applied in place in LDS) against the
-    row tiles it replaces on BasicEncoder.layer1 (spatracker/blocks.py:84-128): identical outputs and InstanceNorm partials, bit for
-    bit -- with and without normalise-on-load, ragged tiles in both directions, runs of tiles that cross image boundaries (more
-    images than a workgroup's run is long), more workgroups than tiles would need (300 single-tile images on 256 CUs: two tiles on
-    some workgroups, one on others)."""
-    n, H, W, norm = cfg
-    g = torch.Generator().manual_seed(n * 1000 + H + W)
-    x = G((torch.randn(n, H, W, 64, generator=g) * 1.5 + 0.3).to(torch.bfloat16))
-    w = torch.randn(64, 3, 3, 64, generator=g) / math.sqrt(64 * 9)
-    b = G(torch.randn(64, generator=g))
-    hi, _ = split(hip, G(pad_w(w.reshape(64, -1))), False)
-    st = G(torch.stack([torch.randn(n, 64, generator=g) * 0.2, torch.rand(n, 64, generator=g) + 0.5], -1)) if norm else None
-    slots = hip.conv2d_stat_slots(H, W, 64, 3, 3, 1, 1, False)
-    outs, parts = [], []
-    for on in ("1", "0"):
-        monkeypatch.setenv("MVT_CONV_C64", on)
-        out = torch.full((n, H, W, 64), float("nan"), device=DEV, dtype=torch.bfloat16)
-        part = torch.full((n * slots * 64 * 2,), float("nan"), device=DEV)
-        hip.conv2d_bf16(x, hi, None, b, out, n, H, W, 64, 64, 3, 3, 1, 1, 64, in_stats=st, out_partial=part)
-        torch.cuda.synchronize()
-        outs.append(out)
-        parts.append(part)
-    assert bool(torch.isfinite(outs[0].float()).all()) and bool(torch.isfinite(parts[0]).all())
-    assert torch.equal(outs[0], outs[1])
-    assert torch.equal(parts[0], parts[1])
-    # (and without statistics requested)
-    monkeypatch.setenv("MVT_CONV_C64", "1")
-    out = torch.full((n, H, W, 64), float("nan"), device=DEV, dtype=torch.bfloat16)
-    hip.conv2d_bf16(x, hi, None, b, out, n, H, W, 64, 64, 3, 3, 1, 1, 64, in_stats=st)
-    torch.cuda.synchronize()
-    assert torch.equal(out, outs[1])
-
-
 @pytest.mark.parametrize("cfg", [(2, 64, 96, 64, 96), (1, 90, 160, 96, 128), (3, 33, 41, 128, 128), (2, 32, 32, 64, 64)])
 def test_conv3x3s2_with_downsample_branch(hip, cfg):
     """mvt_conv3x3s2_down_bf16: conv1 (3x3 / stride 2) and downsample[0] (1x1 / stride 2) of a strided ResidualBlock
