@@ -1,10 +1,12 @@
-timeout -k 10 200 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "c64_persistent" 2>&1 | tail -3
-for rep in 1 2; do
-for on in 1 0; do
-  export MVT_CONV_C64=$on; echo "== MVT_CONV_C64=$on"
-  timeout -k 10 60 python tools/prof_conv.py 24 256 256 64 64 3 1 1 1
-  timeout -k 10 60 python tools/prof_conv.py 24 256 256 64 64 3 1 1 1 0
+python bench.py --config c2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r04_bench_c2.json 2>gpurun_out/r04_bench_c2.err
+python bench.py --config c5shard --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/r04_bench_c5.json 2>gpurun_out/r04_bench_c5.err
+MVT_OVERLAP=0 python bench.py --config c5shard --steps 3 --warmup 1 --no-cpu-baseline --no-corr-calibration > gpurun_out/r04_bench_c5_nooverlap.json 2>/dev/null
+MVT_CONV_BIG_SHARED=0 python bench.py --config c5shard --steps 3 --warmup 1 --no-cpu-baseline --no-corr-calibration > gpurun_out/r04_bench_c5_bigoff.json 2>/dev/null
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-corr-calibration --clips-in-flight 2 > gpurun_out/r04_bench_twoclips.json 2>/dev/null
+for f in c2 c5 c5_nooverlap c5_bigoff twoclips; do python - <<PY
+import json
+d=json.load(open("gpurun_out/r04_bench_$f.json"))
+r=d["roofline"]; m=d["roofline_mfma"]
+print("$f", round(d["ms_per_step"],2), "corr", round(r["frac"],3), r.get("frac_alone_warm"), r.get("frac_last_window"), "upd", round(m["updater"]["frac"],4), round(m["updater"]["ms_per_step"],1), "enc", round(m["encoder"]["frac"],4), round(m["encoder"]["ms_per_step"],1), d.get("throughput_two_clips",{}).get("ms_per_clip"))
+PY
 done
-done
-unset MVT_CONV_C64
-STAMP_RAW=1 STAMP_NORM=1 MVT_LIB=mvtracker_amd/lib/libmvtracker_hip_stamps.so timeout -k 5 100 python tools/stamp_conv.py 24 256 256 64 64 > gpurun_out/r4_stamp_c64b.txt 2>&1

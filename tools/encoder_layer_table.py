@@ -13,10 +13,10 @@ if db.endswith(".csv"):  # rocprofv3 --kernel-trace --output-format csv
     import csv
     rows = [(r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             for r in sorted(csv.DictReader(open(db)), key=lambda r: int(r["Start_Timestamp"]))
-            if "conv_rows_bf16" in r["Kernel_Name"] or "stem7x7" in r["Kernel_Name"]]
+            if "conv_rows_bf16" in r["Kernel_Name"] or "stem7x7" in r["Kernel_Name"] or "conv3x3_big_bf16" in r["Kernel_Name"]]
 else:
     c = sqlite3.connect(db).cursor()
-    rows = list(c.execute("select name, grid_x, end-start from kernels where name like '%conv_rows_bf16%' or name like '%stem7x7%' order by start"))
+    rows = list(c.execute("select name, grid_x, end-start from kernels where name like '%conv_rows_bf16%' or name like '%stem7x7%' or name like '%conv3x3_big_bf16%' order by start"))
 
 
 def fl(ho, cout, cin, k):
@@ -26,7 +26,11 @@ def fl(ho, cout, cin, k):
 LAYERS = {  # (template args, grid threads) -> [(label, flops)]
     ("stem", 1572864): [("conv1 7x7 s2 3->64 @256", fl(256, 64, 3, 7))],
     ("2, 2, 3, 1", 1572864): [("layer1 3x3 64->64 @256 (x4)", fl(256, 64, 64, 3)), ("conv2 3x3 416->256 @128", fl(128, 256, 416, 3))],
+    ("big", 786432): [("conv2 3x3 416->256 @128, one 512-thread workgroup per CU (first block)", fl(128, 256, 416, 3))],
     ("1, 3, 3, 2", 786432): [("layer2.0.conv1 3x3 s2 64->96 @128", fl(128, 96, 64, 3))],
+    ("1, 3, 3, 2 DS", 786432): [("layer2.0.conv1 3x3 s2 + downsample 1x1 s2 64->96 @128 (one launch)", fl(128, 96, 64, 3) + fl(128, 96, 64, 1))],
+    ("1, 2, 3, 2 DS", 393216): [("layer3.0.conv1 3x3 s2 + downsample 96->128 @64 (one launch)", fl(64, 128, 96, 3) + fl(64, 128, 96, 1))],
+    ("1, 2, 3, 2 DS", 98304): [("layer4.0.conv1 3x3 s2 + downsample 128->128 @32 (one launch)", fl(32, 128, 128, 3) + fl(32, 128, 128, 1))],
     ("2, 3, 3, 1", 393216): [("layer2 3x3 96->96 @128 (x3)", fl(128, 96, 96, 3))],
     ("2, 3, 1, 2", 393216): [("layer2 downsample 1x1 s2 64->96", fl(128, 96, 64, 1))],
     ("1, 2, 3, 2", 393216): [("layer3.0.conv1 3x3 s2 96->128 @64", fl(64, 128, 96, 3))],
@@ -39,7 +43,14 @@ LAYERS = {  # (template args, grid threads) -> [(label, flops)]
 }
 acc = defaultdict(list)
 for name, grid, dur in rows:
-    key = "stem" if "stem7x7" in name else re.search(r"conv_rows_bf16<(\d, \d, \d, \d)", name).group(1)
+    if "stem7x7" in name:
+        key = "stem"
+    elif "conv3x3_big" in name:
+        key = "big"
+    else:
+        key = re.search(r"conv_rows_bf16<(\d, \d, \d, \d)", name).group(1)
+        if re.search(r"conv_rows_bf16<\d, \d, \d, \d, \w+, \d, \w+, true>", name):
+            key += " DS"
     cands = LAYERS.get((key, grid))
     if not cands:
         acc[(f"unmapped {key} grid {grid}", 0.0)].append(dur)
