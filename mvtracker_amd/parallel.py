@@ -130,7 +130,13 @@ class ShardedTracker:
                 side = m._side_stream(dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    exchange_block(first_end, T)
+                    # (this block is encoded BESIDE the first windows: short-lived workgroups only, MVT_IO_SHORT_WG -- bit-identical
+                    #  results; see MVTracker.wide_conv_shared)
+                    m._shared_gpu = getattr(m, "wide_conv_shared", "auto") != "1"
+                    try:
+                        exchange_block(first_end, T)
+                    finally:
+                        m._shared_gpu = False
                     m.fill_frame_features(store, r0, first_end, T, level0=level0)
                     ev = torch.cuda.Event()
                     ev.record(side)
