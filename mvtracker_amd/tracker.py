@@ -165,6 +165,7 @@ class MVTracker(nn.Module):
         # (the second stream has more than twice the images of the first block; BASELINE config C5: -6 % per step)
         self.wide_conv_shared = os.environ.get("MVT_CONV_BIG_SHARED", "auto")
         self._shared_gpu = False  # set around the encoder calls issued beside the windows
+        self.side_after_corr = os.environ.get("MVT_SIDE_AFTER_CORR", "1") != "0"  # second-stream encoder starts behind the first correlation
         # MVT_SYNC_DEBUG=1: synchronise the whole device at every cross-stream hand-over of a call ("hand-over
         # table"): if results change with it, an event / wait_stream is missing somewhere (tests: bit-identical with and without)
         self.sync_debug = os.environ.get("MVT_SYNC_DEBUG", "0") != "0"
@@ -612,6 +613,31 @@ class MVTracker(nn.Module):
                            after_first_chunk=after_first_chunk)
         return F0
 
+    def _pinned_i64(self, dev, n):
+        """Cached pinned host buffer of n int64 (per device and stream) for the asynchronous read-back of the query frames."""
+        key = ("pin64", dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        t = self._scratch.get(key)
+        if t is None or t.numel() < n:
+            t = self._scratch[key] = torch.empty(max(n, 1024), dtype=torch.int64).pin_memory()
+        return t[:n]
+
+    def _upload_small(self, dev, *arrays):
+        """Host numpy arrays -> device tensors via one cached pinned buffer (non-blocking copies on the current stream)."""
+        if dev.type != "cuda":
+            return tuple(torch.from_numpy(a).to(dev) for a in arrays)
+        nbytes = sum((a.nbytes + 15) // 16 * 16 for a in arrays)
+        key = ("pin", dev.index, torch.cuda.current_stream(dev).cuda_stream)  # (per stream: single_point mode runs forwards on several)
+        pin = self._scratch.get(key)
+        if pin is None or pin.numel() < nbytes:
+            pin = self._scratch[key] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+        out, o = [], 0
+        for a in arrays:
+            view = pin[o:o + a.nbytes].view(torch.from_numpy(a).dtype)
+            view.copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape(-1))
+            out.append(view.to(dev, non_blocking=True).reshape(a.shape))
+            o += (a.nbytes + 15) // 16 * 16
+        return tuple(out)
+
     def _handover(self, dev):
         """Debug hook at every point where one stream starts consuming what another produced (see ``sync_debug``)."""
         if self.sync_debug and dev.type == "cuda":
@@ -674,26 +700,12 @@ class MVTracker(nn.Module):
             hip.avgpool2(fv[lvl - 1][a:b], fv[lvl][a:b], (b - a) * V, h, w, self.latent_dim)
 
     @hip.guarded
-    def build_frame_store(self, rgbs, depths, intrs, extrs, t0=0, level0=None, t1=None, after_geometry=None):
-        """Features and world-space points of every pyramid level, frame-major.
-
-        rgbs (V,T,3,H,W), depths (V,T,1,H,W), intrs (V,T,3,3), extrs (V,T,3,4).  ``level0`` (T,V,H/4,W/4,C)
-        may carry level-0 features encoded elsewhere (frames split across GPUs, mvtracker_amd.parallel).
-        Features are computed for frames [t0, t1) only (``fill_frame_features`` adds more later); the geometry
-        (points, tile boxes) covers every frame."""
-        V, T, _, H, W = rgbs.shape
-        dev = rgbs.device
+    def store_geometry(self, depths, intrs, extrs):
+        """The query-independent half of the frame store: world-space points of every pyramid level, tile boxes.  A handful of small
+        kernels; ``forward`` enqueues them BEFORE its one host sync (the query frames), so that the GPU has work while the host wakes up."""
+        V, T, _, H, W = depths.shape
+        dev = depths.device
         hs, ws = H // self.stride, W // self.stride
-        C = self.latent_dim
-        t1 = T if t1 is None else t1
-        # (no memset of the 0.8 GB level-0 store: frames [t0, T) are written by the encoder before any window reads them --
-        #  later frames possibly on the second stream, ordered by events -- and frames before t0 are never read)
-        sdt = level0.dtype if level0 is not None else self.store_dtype()
-        fv = [torch.empty(T, V, hs, ws, C, device=dev, dtype=sdt) if level0 is None else level0]
-        for lvl in range(1, self.corr_n_levels):
-            fv.append(torch.empty(T, V, hs >> lvl, ws >> lvl, C, device=dev, dtype=sdt))
-        for f_ in fv[(1 if level0 is not None else 0):]:
-            f_[:t0].zero_()
         kinv = torch.empty(V * T, 9, device=dev)
         einv = torch.empty(V * T, 12, device=dev)
         hip.invert_cameras(intrs.reshape(V * T, 9), extrs.reshape(V * T, 12), kinv, einv, V * T)
@@ -721,14 +733,39 @@ class MVTracker(nn.Module):
             box.append(b)
             tgrid.append(g)
             gbox.append(gb)
-        store = {"fvec": fv, "xyz": xyz, "P": P, "T": T, "depth_s": ds, "box": box, "tile_grid": tgrid, "gbox": gbox}
+        geo = {"xyz": xyz, "P": P, "T": T, "depth_s": ds, "box": box, "tile_grid": tgrid, "gbox": gbox}
+        if dev.type == "cuda":
+            geo["geo_event"] = torch.cuda.Event()
+            geo["geo_event"].record(torch.cuda.current_stream(dev))
+        return geo
+
+    @hip.guarded
+    def build_frame_store(self, rgbs, depths, intrs, extrs, t0=0, level0=None, t1=None, after_geometry=None, geometry=None):
+        """Features and world-space points of every pyramid level, frame-major.
+
+        rgbs (V,T,3,H,W), depths (V,T,1,H,W), intrs (V,T,3,3), extrs (V,T,3,4).  ``level0`` (T,V,H/4,W/4,C)
+        may carry level-0 features encoded elsewhere (frames split across GPUs, mvtracker_amd.parallel).
+        Features are computed for frames [t0, t1) only (``fill_frame_features`` adds more later); the geometry
+        (points, tile boxes) covers every frame."""
+        V, T, _, H, W = rgbs.shape
+        dev = rgbs.device
+        hs, ws = H // self.stride, W // self.stride
+        C = self.latent_dim
+        t1 = T if t1 is None else t1
+        # (no memset of the 0.8 GB level-0 store: frames [t0, T) are written by the encoder before any window reads them --
+        #  later frames possibly on the second stream, ordered by events -- and frames before t0 are never read)
+        sdt = level0.dtype if level0 is not None else self.store_dtype()
+        fv = [torch.empty(T, V, hs, ws, C, device=dev, dtype=sdt) if level0 is None else level0]
+        for lvl in range(1, self.corr_n_levels):
+            fv.append(torch.empty(T, V, hs >> lvl, ws >> lvl, C, device=dev, dtype=sdt))
+        for f_ in fv[(1 if level0 is not None else 0):]:
+            f_[:t0].zero_()
         # geometry first (a handful of small kernels), features after: what only needs the point clouds -- the first, unseeded
         # neighbour searches of new tracks -- can then run beside the encoder.  ``after_geometry(store)`` is called on the host as
         # soon as the FIRST encoder chunk has been enqueued (the GPU is busy from then on); work it issues on another stream
-        # orders itself after store["geo_event"], not after the encoder.
-        if dev.type == "cuda":
-            store["geo_event"] = torch.cuda.Event()
-            store["geo_event"].record(torch.cuda.current_stream(dev))
+        # orders itself after store["geo_event"], not after the encoder.  ``geometry``: already enqueued by the caller (store_geometry).
+        store = dict(geometry) if geometry is not None else self.store_geometry(depths, intrs, extrs)
+        store["fvec"] = fv
         self.fill_frame_features(store, rgbs, t0, t1, level0, after_first_chunk=(lambda: after_geometry(store)) if after_geometry else None)
         return store
 
@@ -1055,6 +1092,10 @@ class MVTracker(nn.Module):
                 hip.corr_gather_dot_opts(store["xyz"], store["fvec"], store["P"], [idx[lvl] for lvl in range(L)], C, ffeats, coords, n, S,
                                          frame0, 1, T, K, self.corr_n_groups, self.corr_add_neighbor_offset, self.corr_add_neighbor_xyz,
                                          fcorr, Fc, 0)
+            hook = getattr(self, "_after_first_corr", None)
+            if hook is not None:  # (forward: the later frame blocks' encoder starts on the second stream now)
+                self._after_first_corr = None
+                hook()
             if (trace is None and "updater_struct" in pk and self.fuse_head and self.fuse_input and self.fuse_tokens
                     and pk["updater_struct"].input_frag.w):
                 # everything after the correlation in ONE library call: token rows assembled inside the updater's first kernel,
@@ -1129,18 +1170,39 @@ class MVTracker(nn.Module):
         rgbs = rgbs[0].to(dev).contiguous() if rgbs.dtype == torch.uint8 else f32(rgbs[0])
         depths, intrs, extrs, query_points = map(f32, (depths[0], intrs[0], extrs[0], query_points[0]))
 
-        # the one host sync of the call: integer query frames (mvtracker.py:489, truncation toward zero)
+        # the one host sync of the call: integer query frames (mvtracker.py:489, truncation toward zero).  The read-back is
+        # asynchronous (pinned buffer + event) and the query-independent geometry kernels are enqueued BEHIND it before the host
+        # waits: in back-to-back calls the host wakes up when the previous call's last kernel ends, and the GPU then has the
+        # geometry to run while the host enqueues the first encoder block (the kernel trace showed ~0.3 ms of idle GPU there)
         qt_dev = query_points[:, 0].long()
-        qt = qt_dev.cpu().numpy()
+        geometry = None
+        if dev.type == "cuda":
+            qt_pin = self._pinned_i64(dev, N)
+            qt_pin.copy_(qt_dev, non_blocking=True)
+            ev_q = torch.cuda.Event()
+            ev_q.record(torch.cuda.current_stream(dev))
+            if frame_store is None:
+                geometry = self.store_geometry(depths, intrs, extrs)
+            ev_q.synchronize()
+            qt = qt_pin.numpy().copy()
+        else:
+            qt = qt_dev.cpu().numpy()
         order = np.argsort(qt, kind="stable")  # mvtracker.py:514 (order among equal t is unobservable)
         qt_s = qt[order]
         # (the two tiny host-to-device copies go first, while the GPU is idle anyway: from pageable memory they block the host until
         #  the stream has drained, which after the first encoder chunk would be milliseconds)
-        order_d = torch.from_numpy(order).to(dev)
-        qt_sd = torch.from_numpy(qt_s.astype(np.int32)).to(dev)
+        # (through a cached PINNED staging buffer, asynchronously: from pageable memory each copy is a host-blocking staged transfer --
+        #  ~60 us of idle GPU apiece in the kernel trace.  The buffer may be rewritten by the next call: its host sync above comes
+        #  after these copies in stream order)
+        order_d, qt_sd = self._upload_small(dev, order.astype(np.int64), qt_s.astype(np.int32))
         # (N,3) query points sorted by start frame -- enqueued HERE, ahead of the geometry: the searches issued on the second stream
         # order themselves after the geometry event only, and they read these rows)
         qxyz = query_points[order_d, 1:].contiguous()
+        if geometry is not None:
+            # hand-over H4: the searches issued on the second stream order themselves after this event -- it has to come AFTER the
+            # gather above (the geometry itself was enqueued, and its own event recorded, before the host sync)
+            geometry["geo_event"] = torch.cuda.Event()
+            geometry["geo_event"].record(torch.cuda.current_stream(dev))
         state = []
 
         def make_state():
@@ -1209,16 +1271,23 @@ class MVTracker(nn.Module):
                 store = frame_store
                 pending = list(frame_store.get("pending", ()))  # (first frame, event) of feature blocks still in flight
             elif not self.overlap_encoder or max(w, 0) + S >= T or dev.type != "cuda":
-                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), after_geometry=presearch)
+                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), after_geometry=presearch, geometry=geometry)
             else:
                 # The first window needs frames [w, w+S).  The remaining frames are encoded on a second HIP stream while
                 # the updater of the earlier windows runs: its kernels over the 64 virtual tracks fill a fraction of the
                 # CUs, the encoder's convolutions take the rest.
                 ready = max(w, 0) + S
-                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), t1=ready, after_geometry=presearch)
+                store = self.build_frame_store(rgbs, depths, intrs, extrs, t0=max(w, 0), t1=ready, after_geometry=presearch, geometry=geometry)
                 side_chunks = list(range(ready, T, S // 2))  # first frames of the S/2-frame blocks still to encode
                 if not self.defer_encoder:
-                    self._encode_on_side_stream(store, rgbs, side_chunks, pending)
+                    # started by the first window BEHIND its first correlation launch (``_refine`` calls the hook): the first kernels
+                    # of that window -- feature init, window state, the first correlation gather -- are latency-bound and otherwise
+                    # start in the same instant as the second stream's first convolutions
+                    if self.side_after_corr:
+                        chunks_now = side_chunks
+                        self._after_first_corr = lambda: self._encode_on_side_stream(store, rgbs, chunks_now, pending)
+                    else:
+                        self._encode_on_side_stream(store, rgbs, side_chunks, pending)
                     side_chunks = []
         sd_ = make_state()
         traj, vis_prob, vis_logit = sd_["traj"], sd_["vis_prob"], sd_["vis_logit"]
@@ -1276,6 +1345,10 @@ class MVTracker(nn.Module):
             windows.append((w, p1))
             w += S // 2
             p0 = p1
+        hook = getattr(self, "_after_first_corr", None)
+        if hook is not None:  # (no window ran: cannot happen while w < T - S/2, kept for safety)
+            self._after_first_corr = None
+            hook()
         for _, ev in pending:  # frames no window consumed: still join the side stream before the inputs are released
             torch.cuda.current_stream(dev).wait_event(ev)  # hand-over H7: the caller's inputs (read by the second stream) are released
         self.last_windows = windows
