@@ -1483,6 +1483,15 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
   if (attn->kind == MVT_ATTN_TIME) {
     // tiles of whole tracks: S <= 32 keys per track (one MFMA key block), 64 / S tracks per 64-row tile
     MVT_REQUIRE(S <= 32 && !workspace);
+    // Round 4, the small-M form: 32-row tiles (S = 12: two whole tracks, 24 rows) while they fit ONE round of workgroups at one per
+    // CU -- twice the weight bytes in total, half the work per workgroup: a whole updater call 903 -> 819 us at 342 tracks, 932 -> 861
+    // at 448; at 512 tracks (288 workgroups) 929 -> 977: not there.  MVT_TIME_NMB1=0: the 64-row tiles everywhere.
+    static const bool small_tiles = !(getenv("MVT_TIME_NMB1") && atoi(getenv("MVT_TIME_NMB1")) == 0);
+    if (small_tiles && mvt_cdiv(M, (32 / S) * S) <= 256) {
+      a.bmv = (32 / S) * S;
+      hipLaunchKernelGGL((block_fused_bf16<1, 0, 1>), dim3((unsigned)mvt_cdiv(M, a.bmv)), dim3(NT), 0, mvt_stream(stream), a);
+      return mvt_launch_status();
+    }
     a.bmv = (64 / S) * S;
     hipLaunchKernelGGL((block_fused_bf16<2, 0, 1>), dim3((unsigned)mvt_cdiv(M, a.bmv)), dim3(NT), 0, mvt_stream(stream), a);
   } else if (attn->kind == MVT_ATTN_PARTIALS) {
@@ -1502,7 +1511,15 @@ extern "C" int mvt_attn_block_fused_bf16(float* x, int ldx, const mvt_block_attn
   } else if (attn->kind == MVT_ATTN_FRAME) {
     MVT_REQUIRE(attn->n_keys >= 1 && attn->n_keys <= 64);
     const long long ntok = M / S;
-    if (ntok * S >= 4096) {
+    // Round 4, the small-M form (BASELINE config C5: 512 tracks per GPU = 6 144 point rows): 32-token tiles.  At 64 tokens per tile
+    // the launch is 96 workgroups on 256 CUs; 192 workgroups of 32 tokens stream twice the weight bytes in total but finish the launch
+    // sooner -- a whole updater call 929 -> 882 us (tools/time_updater.py 512).  MVT_FRAME_NMB1=0: the 64-token tiles.
+    // Only while the 32-token tiles still fit ONE round of workgroups at one per CU (680 tracks: 264 workgroups, 927 -> 1 026 us).
+    static const bool small_tiles = !(getenv("MVT_FRAME_NMB1") && atoi(getenv("MVT_FRAME_NMB1")) == 0);
+    if (ntok * S >= 4096 && small_tiles && mvt_cdiv(ntok, 32) * S <= 256) {
+      MVT_REQUIRE(!workspace);
+      hipLaunchKernelGGL((block_fused_bf16<1, 0, 2>), dim3((unsigned)mvt_cdiv(ntok, 32), 1, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
+    } else if (ntok * S >= 4096) {
       MVT_REQUIRE(!workspace);
       hipLaunchKernelGGL((block_fused_bf16<2, 0, 2>), dim3((unsigned)mvt_cdiv(ntok, 64), 1, (unsigned)S), dim3(NT), 0, mvt_stream(stream), a);
     } else {

@@ -7,6 +7,7 @@
 //   virtual self attention -> virtual block (-> p2v k|v and the NEXT layer's time q|k|v of the virtual rows)
 //   point<-virtual attention -> point block (-> the next layer's time q|k|v of the point rows)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -117,7 +118,12 @@ static int updater_run(const mvt_updater_weights* w, const float* x, int ldx, co
   const bool fuse_time = (w->fuse_attention & 1) && S <= 32, fuse_p2v = (w->fuse_attention & 2) != 0, fuse_vs = (w->fuse_attention & 4) != 0;
   // bit 5: the virtual-self block's pass 2 runs inside the point<-virtual block (needs both attentions in their block kernels)
   // (the first workgroups of a frame also evaluate the next layer's time q|k|v of the virtual rows, 8 column blocks each: enough tiles)
-  const bool fold_vs = (w->fuse_attention & 32) && fuse_p2v && fuse_vs && (long long)n * S >= 4096 && MLP / 256 <= 4 &&
+  // (not in the small-M form: while 32-token tiles of the point<-virtual block fit one round of workgroups -- ceil(n / 32) * S <= 256,
+  //  the same rule as in mvt_attn_block_fused_bf16 -- that block runs on them, twice the workgroups, and the virtual-self block keeps
+  //  its own second launch: measured faster at 400 / 512 tracks, 958 -> 906 / 929 -> 882 us per call)
+  static const bool small_m = !(getenv("MVT_FRAME_NMB1") && atoi(getenv("MVT_FRAME_NMB1")) == 0);
+  const bool small_form = small_m && (long long)n * S >= 4096 && (long long)((n + 31) / 32) * S <= 256;
+  const bool fold_vs = (w->fuse_attention & 32) && fuse_p2v && fuse_vs && (long long)n * S >= 4096 && !small_form && MLP / 256 <= 4 &&
                        8 * ((n + 63) / 64) >= (3 * INNER + 31) / 32;
 
   // tokens: input transform of the point rows, learned virtual tokens repeated over the S frames (blocks.py:456-459), and the
