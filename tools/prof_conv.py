@@ -32,13 +32,14 @@ slots = hip.conv2d_stat_slots(H, W, Cin, k, k, s, p, False)
 part = torch.empty(n * max(slots, 1) * Cout * 2, device=dev)
 st = torch.rand(n, Cin, 2, device=dev) + 0.5
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for it in range(6):
+NIT = int(os.environ.get("PROF_CONV_ITERS", "6"))  # (6: a small target for PMC passes; more for timing A/B runs)
+for it in range(NIT):
     if it == 1:
         ev0.record()
     hip.conv2d_bf16(x, hi, None, b, out, n, H, W, Cin, Cout, k, k, s, p, Cout, in_stats=st if (k == 3 and s == 1 and norm) else None,
                     out_partial=part if slots else None)
 ev1.record()
 torch.cuda.synchronize()
-t = ev0.elapsed_time(ev1) / 5 * 1e3
+t = ev0.elapsed_time(ev1) / (NIT - 1) * 1e3
 fl = 2.0 * n * Ho * Wo * Cout * (147 if stem else K)
 print(f"conv n={n} {H}x{W} {Cin}->{Cout} k{k}s{s} bf16_tensors={bf}: {t:.1f} us  {fl / t / 1e6:.0f} TFLOP/s")
