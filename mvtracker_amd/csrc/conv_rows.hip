@@ -105,6 +105,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
     constexpr int BN = TN * 32, LDTT = 36;   // staging row = 32 pixels + 4 pad (bf16)
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     const bool interior = x0 + TC <= Wo;
+    // Round 4: written as `if (valid) { s1 += v; s2 = fma(v, v, s2); }` per element, every accumulator register became its own
+    // divergent branch (EXEC save / restore around two instructions: 170-255 instructions per 32 x 32 block, a quarter of a
+    // 64-channel tile's life).  A tile that lies inside the image with all its channels -- wave-uniform, nearly every tile -- takes no
+    // predicate at all; the others select 0 into the sums (s + 0 and fma(0, 0, s) leave s unchanged: same statistics).
+    const bool full = interior && n0 + TN * 32 <= p.Cout;
     const int gq = lane >> 4, li = lane & 15;  // 16-lane group, lane in group
     // the biases of all channel blocks are requested up front: one memory round trip per tile instead of one per 32 x 32 block
     // (a persistent workgroup has no neighbour to hide them behind)
@@ -125,12 +130,19 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
         for (int g = 0; g < 4; ++g) {
           f32x4 v4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = acc[i][j][4 * g + e] + bv;
-            v4[e] = v;
-            if (nok && (interior || x0 + 8 * g + 4 * h + e < Wo)) {
-              s1 += v;
-              s2 = fmaf(v, v, s2);
+          for (int e = 0; e < 4; ++e) v4[e] = acc[i][j][4 * g + e] + bv;
+          if (full) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s1 += v4[e];
+              s2 = fmaf(v4[e], v4[e], s2);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float vm = (nok && (interior || x0 + 8 * g + 4 * h + e < Wo)) ? v4[e] : 0.f;
+              s1 += vm;
+              s2 = fmaf(vm, vm, s2);
             }
           }
           *reinterpret_cast<u32x2*>(&stage[(j * 32 + r) * LDTT + 8 * g + 4 * h]) = __builtin_bit_cast(u32x2, __builtin_convertvector(v4, bf16x4));
@@ -170,7 +182,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
 #pragma unroll
       for (int k = 0; k < BN / 16; ++k) {
         const int m = 2 * k + (gq >> 1);
-        if (x0 + px < Wo && n0 + 8 * m < p.Cout) {
+        if (full || (x0 + px < Wo && n0 + 8 * m < p.Cout)) {
           const u32x2 a = __builtin_bit_cast(u32x2, lo[k]), b2 = __builtin_bit_cast(u32x2, hi[k]);
           *reinterpret_cast<u32x4*>(lanep + 8 * m) = (u32x4){a[0], a[1], b2[0], b2[1]};
         }
@@ -186,6 +198,7 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
     // 128-B lines (the scattered stores were still a quarter of the 64-channel layers' time).  `stage` is wave-private.
     constexpr int BN = TN * 32, LDT = BN + 8, PPX = BN / 8;  // row stride (bf16), 16-B pieces per pixel
     const bool interior = x0 + TC <= Wo;
+    const bool full = interior && n0 + TN * 32 <= p.Cout;  // (wave-uniform: no per-element predicates, see the transposed form above)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int y = yw + i;  // wave-uniform
@@ -201,10 +214,9 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
           const int dx = (e & 3) + 8 * (e >> 2) + 4 * h;
           const float v = acc[i][j][e] + bv;
           stage[dx * LDT + j * 32 + r] = mvt_bf16_bits(v);
-          if (nok && (interior || x0 + dx < Wo)) {
-            s1 += v;
-            s2 = fmaf(v, v, s2);
-          }
+          const float vm = (full || (nok && (interior || x0 + dx < Wo))) ? v : 0.f;
+          s1 += vm;
+          s2 = fmaf(vm, vm, s2);
           if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four accumulator registers at a time (VGPR budget)
         }
         if (p.out_part) {  // one writer per (tile row, channel): deterministic
@@ -260,10 +272,9 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[e] = acc[i][j][4 * g + e] + bv;
-            if (nok && (interior || x0 + 4 * h + 8 * g + e < Wo)) {
-              s1 += v[e];
-              s2 = fmaf(v[e], v[e], s2);
-            }
+            const float vm = (nok && (interior || x0 + 4 * h + 8 * g + e < Wo)) ? v[e] : 0.f;  // (a select, not a branch per element)
+            s1 += vm;
+            s2 = fmaf(vm, vm, s2);
           }
           float lo[2], hi[2];  // per pixel pair pp (pixels 2pp + odd): channels (n & ~1), (n & ~1) + 1
 #pragma unroll
@@ -299,14 +310,11 @@ __device__ __forceinline__ void epilogue_rows(const f32x16 (&acc)[TM][TN], const
           const int dx = (e & 3) + 8 * (e >> 2);
           const float v0 = acc[i][j][e] + bv, v1 = acc[i][j][e + 1] + bv;
           const bool ok0 = nok && (interior || x0 + 4 * h + dx < Wo), ok1 = nok && (interior || x0 + 4 * h + dx + 1 < Wo);
-          if (ok0) {
-            s1 += v0;
-            s2 = fmaf(v0, v0, s2);
-          }
-          if (ok1) {
-            s1 += v1;
-            s2 = fmaf(v1, v1, s2);
-          }
+          const float m0 = ok0 ? v0 : 0.f, m1 = ok1 ? v1 : 0.f;
+          s1 += m0;
+          s2 = fmaf(m0, m0, s2);
+          s1 += m1;
+          s2 = fmaf(m1, m1, s2);
           // even lane sends v1 (pixel e+1) and keeps v0; odd lane sends v0 and keeps v1
           const float send = odd ? v0 : v1;
           const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
