@@ -629,6 +629,33 @@ def test_c3_bf16_full_size(model, W):
         print(f"C3 bf16: every window / iteration teacher-forced, fcorr rows max abs err {w:.2e}")
 
 
+def test_c4_all_queries_on_one_gpu_bf16(model, W):
+    """BASELINE config C4's TOTAL query count (8 192; one GPU's share of the 8-GPU run is C3's 1 024) in a single forward on one GPU, as
+    the reference itself would run it (mvtracker.py:503: any N): 99 k point rows per updater call -- eight rounds of the 64-row big
+    blocks, 8 192 keys per frame in the key-split virtual<-point attention, 393 k (track, frame) searches per level and iteration.
+    Size-independent properties, every window / iteration teacher-forced on sampled rows, and one updater call of that size against
+    the oracle (rule of _bf16_stage_check)."""
+    N = 8192
+    clip = synth.make_clip(11, V=4, T=24, H=512, W=512, N=N, late_queries=True)
+    a = args_of(clip, DEV)
+    with _with_precision(model, "bf16"):
+        r1 = model(*a, iters=4)
+        t1, v1 = r1["traj_e"].clone(), r1["vis_e"].clone()
+        model.check_finite()
+        assert t1.shape == (1, 24, N, 3) and bool(torch.isfinite(t1).all()) and bool(torch.isfinite(v1).all())
+        assert float(v1.min()) >= 0.0 and float(v1.max()) <= 1.0
+        r2 = model(*a, iters=4)
+        assert torch.equal(t1, r2["traj_e"]) and torch.equal(v1, r2["vis_e"])
+        q = a[2][0]
+        qt = q[:, 0].long()
+        late = torch.nonzero(qt == 13)[:, 0]
+        assert len(late) > 0 and float(t1[0, :6, late].abs().max()) == 0.0
+        at_q = t1[0, qt, torch.arange(N, device=DEV)]
+        assert float((at_q - q[:, 1:]).abs().max()) < 0.25
+        w = _check_forward_trace(model, a, updater=(W, [(1, 1)], (2.5e-2, 2e-2)))
+        print(f"C4 total on one GPU, bf16: every window / iteration teacher-forced, fcorr rows max abs err {w:.2e}")
+
+
 def test_c2_full_size_fp32_invalid_depth(model, W):
     """BASELINE config C2: 3 views x 24 frames x 384x512, 512 queries, fp32, 2 % invalid depth (zero-depth pixels collapse onto
     the camera centre: dense equidistant-candidate clusters).  Properties + sampled rows against the oracle on the same store."""
