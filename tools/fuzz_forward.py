@@ -1,0 +1,56 @@
+"""Random clip shapes through the whole forward, every window / iteration teacher-forced against the oracle on the device's own
+state (tests/test_gpu_e2e.py::_check_forward_trace: kNN indices bit-exact, sampled correlation rows), plus finiteness and
+run-to-run bit-identity.  A robustness sweep for the GPU box, not part of the test suite:
+
+    python tools/fuzz_forward.py [n_configs] [first_seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from mvtracker_amd import synth  # noqa: E402
+from mvtracker_amd.tracker import MVTracker  # noqa: E402
+import test_gpu_e2e as E  # noqa: E402
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+m = MVTracker(hidden_size=256).eval()
+sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+m = m.to(E.DEV)
+fails = 0
+for k in range(n_cfg):
+    rng = np.random.default_rng(1000 + seed0 + k)
+    V = int(rng.integers(1, 6))
+    T = int(rng.integers(13, 32))          # at least two windows
+    H = int(rng.integers(4, 24)) * 16      # 64 .. 368, multiples of 16 (pyramid of 4 levels below stride 4: odd sizes included)
+    W = int(rng.integers(4, 30)) * 16
+    N = int(rng.choice([1, 2, 7, 33, 100, 341, 512, 700, 1500]))
+    prec = str(rng.choice(["fp32", "bf16"]))
+    late = bool(rng.integers(2))
+    inval = float(rng.choice([0.0, 0.03]))
+    tag = f"cfg {k}: V={V} T={T} {H}x{W} N={N} {prec} late={late} invalid={inval}"
+    t0 = time.time()
+    try:
+        clip = synth.make_clip(2000 + seed0 + k, V=V, T=T, H=H, W=W, N=N, late_queries=late, invalid_frac=inval)
+        a = E.args_of(clip, E.DEV)
+        with E._with_precision(m, prec):
+            r1 = m(*a, iters=4)
+            t1, v1 = r1["traj_e"].clone(), r1["vis_e"].clone()
+            m.check_finite()
+            assert bool(torch.isfinite(t1).all()) and bool(torch.isfinite(v1).all())
+            r2 = m(*a, iters=4)
+            assert torch.equal(t1, r2["traj_e"]) and torch.equal(v1, r2["vis_e"]), "two runs differ"
+            w = E._check_forward_trace(m, a, n_sample=max(2, min(32, N)))
+        print(f"ok   {tag}: fcorr rows max abs err {w:.2e} ({time.time() - t0:.1f} s)", flush=True)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print(f"FAIL {tag}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+print(f"{n_cfg - fails} / {n_cfg} configurations passed")
+sys.exit(1 if fails else 0)
