@@ -1,0 +1,53 @@
+"""The bf16 encoder as the benchmark runs it (composite mvt_encoder_forward_rgb) at random image sizes -- multiples of 8 that leave
+partial tiles at every layer, fp32 and uint8 frames -- against the oracle's BasicEncoder on the same images: the rule of
+tests/test_gpu_e2e.py::_bf16_stage_check (at most 10 % worse than the oracle under bf16 autocast, plus an absolute cap).
+
+    python tools/fuzz_encoder.py [n_configs] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from mvtracker_amd import synth  # noqa: E402
+from mvtracker_amd.tracker import MVTracker, _ClipImages  # noqa: E402
+import test_gpu_e2e as E  # noqa: E402
+from oracle import mvt_oracle as O  # noqa: E402
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+m = MVTracker(hidden_size=256).eval()
+sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+m = m.to(E.DEV)
+m.precision = "bf16"
+W = O.make_weights(E.CFG, seed=0)
+fails = 0
+for k in range(n_cfg):
+    rng = np.random.default_rng(300 + seed + k)
+    V = int(rng.integers(1, 4))
+    H, Wd = int(rng.integers(4, 50)) * 8, int(rng.integers(4, 60)) * 8
+    dtype = np.uint8 if rng.integers(2) else np.float32
+    tag = f"cfg {k}: {V} images of {H}x{Wd} {np.dtype(dtype).name}"
+    try:
+        clip = synth.make_clip(700 + seed + k, V=V, T=1, H=H, W=Wd, N=1, rgb_dtype=dtype)
+        rgbs = torch.from_numpy(clip["rgbs"])[0]
+        x = 2 * (rgbs.float().reshape(V, 3, H, Wd) / 255.0) - 1
+        with torch.no_grad():
+            ref = O.encoder(W, x).numpy()
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                ac = O.encoder(W, x).float().numpy()
+        pk = m._pack(torch.device(E.DEV))
+        out = torch.zeros(V, H // 4, Wd // 4, 128, device=E.DEV, dtype=m.store_dtype())
+        m._encode(pk, _ClipImages(rgbs.to(E.DEV).contiguous(), V, 1, 0), V, H, Wd, out)
+        torch.cuda.synchronize()
+        E._bf16_stage_check(tag, out.float().permute(0, 3, 1, 2).cpu().numpy(), ref, ac, (6e-2, 5e-2))
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print(f"FAIL {tag}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+print(f"{n_cfg - fails} / {n_cfg} configurations passed")
+sys.exit(1 if fails else 0)
