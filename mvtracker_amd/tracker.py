@@ -706,6 +706,12 @@ class MVTracker(nn.Module):
         V, T, _, H, W = depths.shape
         dev = depths.device
         hs, ws = H // self.stride, W // self.stride
+        # (the reference fails here too, inside its kNN -- pointops / topk with k above the number of points, mvtracker.py:26-90 --; say why)
+        pmin = V * (hs >> (self.corr_n_levels - 1)) * (ws >> (self.corr_n_levels - 1))
+        if pmin < self.corr_neighbors:
+            raise ValueError(f"the coarsest level of the point-cloud pyramid has {pmin} points per frame ({V} views of "
+                             f"{hs >> (self.corr_n_levels - 1)} x {ws >> (self.corr_n_levels - 1)}), fewer than corr_neighbors = "
+                             f"{self.corr_neighbors}: frames of {H} x {W} are too small for {self.corr_n_levels} correlation levels")
         kinv = torch.empty(V * T, 9, device=dev)
         einv = torch.empty(V * T, 12, device=dev)
         hip.invert_cameras(intrs.reshape(V * T, 9), extrs.reshape(V * T, 12), kinv, einv, V * T)
