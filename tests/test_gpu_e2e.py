@@ -656,6 +656,24 @@ def test_c4_all_queries_on_one_gpu_bf16(model, W):
         print(f"C4 total on one GPU, bf16: every window / iteration teacher-forced, fcorr rows max abs err {w:.2e}")
 
 
+@pytest.mark.parametrize("T_,late", [(4, False), (6, False), (9, True)])
+def test_no_window_runs_near_the_clips_end_zeros_like_the_oracle(model, W, T_, late):
+    """A reference quirk the product copies (mvtracker.py:537: `while ind < T - S // 2`): when the first query frame lies within S / 2 = 6
+    frames of the clip's end -- every clip of <= 6 frames, or only late queries -- no window runs and tracks / visibilities stay zero.  The
+    oracle's loop is the reference's; the device path must agree exactly (found while writing tools/fuzz_forward.py)."""
+    clip = synth.make_clip(77, V=2, T=T_, H=96, W=128, N=5)
+    if late:
+        clip["query_points"][0, :, 0] = T_ - 2  # every query enters two frames before the end
+    a = args_of(clip, DEV)
+    r = model(*a, iters=2)
+    with torch.no_grad():
+        ref = O.tracker_forward(W, CFG, *args_of(clip), iters=2)
+    assert len(model.last_windows) == 0
+    assert float(ref["traj_e"].abs().max()) == 0.0 and float(ref["vis_e"].abs().max()) == 0.0
+    assert float(r["traj_e"].abs().max()) == 0.0 and float(r["vis_e"].abs().max()) == 0.0
+    assert r["traj_e"].shape == ref["traj_e"].shape and r["vis_e"].shape == ref["vis_e"].shape
+
+
 def test_c2_full_size_fp32_invalid_depth(model, W):
     """BASELINE config C2: 3 views x 24 frames x 384x512, 512 queries, fp32, 2 % invalid depth (zero-depth pixels collapse onto
     the camera centre: dense equidistant-candidate clusters).  Properties + sampled rows against the oracle on the same store."""
