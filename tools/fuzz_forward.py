@@ -34,7 +34,7 @@ for k in range(n_cfg):
     W = int(rng.integers(8, 60)) * 8 if wide else int(rng.integers(4, 30)) * 16
     iters = int(rng.integers(1, 7)) if wide else 4
     N = int(rng.choice([1, 2, 7, 33, 100, 341, 512, 700, 1500]))
-    prec = str(rng.choice(["fp32", "bf16"]))
+    prec = str(rng.choice(["fp32", "bf16", "bf16x3"] if os.environ.get("FUZZ_BF16X3", "0") != "0" else ["fp32", "bf16"]))
     late = bool(rng.integers(2))
     inval = float(rng.choice([0.0, 0.03]))
     tag = f"cfg {k}: V={V} T={T} {H}x{W} N={N} {prec} late={late} invalid={inval} iters={iters}"
