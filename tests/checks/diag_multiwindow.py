@@ -1,11 +1,11 @@
 """First divergence between the product (fp32 mode) and the oracle on a multi-window clip: per window and iteration, the kNN
-index sets, correlation features, deltas.  python tools/diag_multiwindow.py [S] [seed]"""
+index sets, correlation features, deltas.  python tests/checks/diag_multiwindow.py [S] [seed]"""
 import sys
 import numpy as np
 import torch
 sys.path.insert(0, "/root/repo")
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mvtracker_amd import synth
 from mvtracker_amd.tracker import MVTracker
 from oracle import mvt_oracle as O

@@ -1,6 +1,6 @@
 """Stage-by-stage parity report (GPU box): product vs oracle on one seeded clip.
 
-    python tools/diagnose_parity.py --seed 52 --views 3 --frames 20 --height 128 --width 160 --queries 24 --late
+    python tests/checks/diagnose_parity.py --seed 52 --views 3 --frames 20 --height 128 --width 160 --queries 24 --late
 Prints, per window / iteration, the number of kNN index mismatches per level and the max errors of the
 correlation features, tokens, deltas; then final track / visibility-logit errors."""
 import argparse
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mvtracker_amd import synth  # noqa: E402
 from mvtracker_amd.tracker import MVTracker  # noqa: E402
 from oracle import mvt_oracle as O  # noqa: E402

@@ -1,7 +1,7 @@
 """Random shapes through the bf16 convolution entry (mvt_conv2d_bf16: row tiles, the wide 512-thread kernel, stride 2, 1x1,
 normalise-on-load, fused statistics) against an fp64 convolution of the same bf16 operands.  A robustness sweep for the GPU box:
 
-    python tools/fuzz_conv.py [n_configs] [first_seed]
+    python tests/checks/fuzz_conv.py [n_configs] [first_seed]
 """
 import math
 import os
@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mvtracker_amd import hip  # noqa: E402
 
 DEV = "cuda"

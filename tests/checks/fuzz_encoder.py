@@ -2,7 +2,7 @@
 partial tiles at every layer, fp32 and uint8 frames -- against the oracle's BasicEncoder on the same images: the rule of
 tests/test_gpu_e2e.py::_bf16_stage_check (at most 10 % worse than the oracle under bf16 autocast, plus an absolute cap).
 
-    python tools/fuzz_encoder.py [n_configs] [seed]
+    python tests/checks/fuzz_encoder.py [n_configs] [seed]
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mvtracker_amd import synth  # noqa: E402

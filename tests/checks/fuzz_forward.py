@@ -2,7 +2,7 @@
 state (tests/test_gpu_e2e.py::_check_forward_trace: kNN indices bit-exact, sampled correlation rows), plus finiteness and
 run-to-run bit-identity.  A robustness sweep for the GPU box, not part of the test suite:
 
-    python tools/fuzz_forward.py [n_configs] [first_seed]
+    python tests/checks/fuzz_forward.py [n_configs] [first_seed]
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mvtracker_amd import synth  # noqa: E402

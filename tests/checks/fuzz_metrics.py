@@ -2,14 +2,14 @@
 evaluation settings against the CPU restatement of the reference's evaluation/metrics.py (oracle/metrics_oracle.py): the per-track
 table for every track and evaluate_3dpt's flat dictionary.
 
-    python tools/fuzz_metrics.py [n_configs] [seed]
+    python tests/checks/fuzz_metrics.py [n_configs] [seed]
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mvtracker_amd import metrics  # noqa: E402
 from oracle import metrics_oracle as MO  # noqa: E402

@@ -4,7 +4,7 @@ run-to-run bit-identical, every window / iteration teacher-forced against the or
 rows in the option's layout), and one updater call of the forward against the oracle's update_former with the same configuration
 (fp32: 2e-5 of the output scale; bf16: the 1.1 x rule of _bf16_stage_check).
 
-    python tools/fuzz_model_options.py [n_configs] [seed]
+    python tests/checks/fuzz_model_options.py [n_configs] [seed]
 """
 import os
 import sys
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mvtracker_amd import synth  # noqa: E402

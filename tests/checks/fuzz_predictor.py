@@ -2,7 +2,7 @@
 bilinearly sampled depth; evaluation_predictor_3dpt.py:59-120) on random clip sizes, interp shapes and grid settings: what the
 predictor hands to MVTracker.forward against the oracle's predictor_prepare (deterministic: no neighbour ranking involved).
 
-    python tools/fuzz_predictor.py [n_configs] [seed]
+    python tests/checks/fuzz_predictor.py [n_configs] [seed]
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mvtracker_amd import synth  # noqa: E402
 from mvtracker_amd.predictor import EvaluationPredictor  # noqa: E402

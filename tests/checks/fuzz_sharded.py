@@ -2,7 +2,7 @@
 frame store handed to the forward -> gathered outputs) rehearsed on ONE GPU with a one-rank RCCL group (MVT_FORCE_SHARDED=1) on random
 clips: bit-identical to the direct call.
 
-    python tools/fuzz_sharded.py [n_configs] [seed]
+    python tests/checks/fuzz_sharded.py [n_configs] [seed]
 """
 import os
 import sys
@@ -12,7 +12,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mvtracker_amd import synth  # noqa: E402
 from mvtracker_amd.parallel import ShardedTracker  # noqa: E402

@@ -2,7 +2,7 @@
 second-stream encoder / pre-searches against the same call with every hand-over synchronised (sync_debug) and against
 overlap_encoder = False; (b) EvaluationPredictor(single_point=True) on 1 stream against 2..8 streams.  A race shows up as a difference.
 
-    python tools/fuzz_streams.py [n_configs] [seed]
+    python tests/checks/fuzz_streams.py [n_configs] [seed]
 """
 import os
 import sys
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mvtracker_amd import synth  # noqa: E402
 from mvtracker_amd.predictor import EvaluationPredictor  # noqa: E402

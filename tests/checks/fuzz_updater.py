@@ -3,7 +3,7 @@ pass 2, key-split attention) at track counts on and around its form thresholds a
 EfficientUpdateFormer on the same tokens: the rule of tests/test_gpu_e2e.py::_bf16_stage_check (at most 10 % worse than the oracle
 under bf16 autocast, in max and in mean, plus an absolute cap).
 
-    python tools/fuzz_updater.py [n_random] [seed]
+    python tests/checks/fuzz_updater.py [n_random] [seed]
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mvtracker_amd import synth  # noqa: E402

@@ -1,7 +1,7 @@
 """Find seeds whose product-vs-oracle run has no kNN neighbour flip (GPU box)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mvtracker_amd import synth
 from mvtracker_amd.tracker import MVTracker
 from oracle import mvt_oracle as O

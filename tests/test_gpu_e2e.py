@@ -660,7 +660,7 @@ def test_c4_all_queries_on_one_gpu_bf16(model, W):
 def test_no_window_runs_near_the_clips_end_zeros_like_the_oracle(model, W, T_, late):
     """A reference quirk the product copies (mvtracker.py:537: `while ind < T - S // 2`): when the first query frame lies within S / 2 = 6
     frames of the clip's end -- every clip of <= 6 frames, or only late queries -- no window runs and tracks / visibilities stay zero.  The
-    oracle's loop is the reference's; the device path must agree exactly (found while writing tools/fuzz_forward.py)."""
+    oracle's loop is the reference's; the device path must agree exactly (found while writing tests/checks/fuzz_forward.py)."""
     clip = synth.make_clip(77, V=2, T=T_, H=96, W=128, N=5)
     if late:
         clip["query_points"][0, :, 0] = T_ - 2  # every query enters two frames before the end
@@ -1050,7 +1050,7 @@ def test_forward_other_window_lengths(S, seed):
     within 3x the error of the oracle run under bf16 autocast (the rule of test_forward_bf16_vs_autocast_oracle).  The seeds are
     clips without a near-tie in any neighbour ranking: on these regular synthetic clouds two candidates often sit within an ulp of
     the same distance, a 1e-7 difference in a track coordinate then swaps their order, the correlation features swap with them
-    and both sides drift apart by ~1e-3 (tools/diag_multiwindow.py prints the first such swap; the reference is equally
+    and both sides drift apart by ~1e-3 (tests/checks/diag_multiwindow.py prints the first such swap; the reference is equally
     sensitive) -- that is a property of the algorithm, not a tolerance this test can state."""
     from mvtracker_amd.tracker import MVTracker
     cfg = O.TrackerConfig(sliding_window_len=S)

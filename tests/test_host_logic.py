@@ -66,7 +66,7 @@ def test_forward_corr_options(monkeypatch, golden, name):
 def test_frames_too_small_for_the_pyramid_raise_a_clear_error(monkeypatch):
     """One view of 112 x 80 pixels leaves 3 x 2 = 6 points at the coarsest correlation level, fewer than K = 16 neighbours: the
     reference fails inside its kNN there (mvtracker.py:26-90: topk / knn_query with k above the number of points); here the frame
-    store says what is wrong before any kernel is asked for it (found by tools/fuzz_predictor.py)."""
+    store says what is wrong before any kernel is asked for it (found by tests/checks/fuzz_predictor.py)."""
     hip_mock.install(monkeypatch)
     m = MVTracker(hidden_size=256).eval()
     clip = synth.make_clip(1, V=1, T=8, H=112, W=80, N=2)
