@@ -33,14 +33,20 @@ for k in range(n_cfg):
     H = int(rng.integers(8, 48)) * 8 if wide else int(rng.integers(4, 24)) * 16  # (default 64 .. 368 in multiples of 16: odd pyramid levels included)
     W = int(rng.integers(8, 60)) * 8 if wide else int(rng.integers(4, 30)) * 16
     iters = int(rng.integers(1, 7)) if wide else 4
+    big = os.environ.get("FUZZ_BIG", "0") != "0"  # benchmark-sized clips: up to 6 views of 720 x 1 280, up to 4 096 queries
+    if big:
+        V = int(rng.integers(2, 7))
+        H, W = int(rng.integers(16, 46)) * 16, int(rng.integers(16, 81)) * 16
     N = int(rng.choice([1, 2, 7, 33, 100, 341, 512, 700, 1500]))
+    if os.environ.get("FUZZ_BIG", "0") != "0":
+        N = int(rng.choice([512, 1024, 2048, 4096]))
     prec = str(rng.choice(["fp32", "bf16", "bf16x3"] if os.environ.get("FUZZ_BF16X3", "0") != "0" else ["fp32", "bf16"]))
     late = bool(rng.integers(2))
     inval = float(rng.choice([0.0, 0.03]))
     tag = f"cfg {k}: V={V} T={T} {H}x{W} N={N} {prec} late={late} invalid={inval} iters={iters}"
     t0 = time.time()
     try:
-        clip = synth.make_clip(2000 + seed0 + k, V=V, T=T, H=H, W=W, N=N, late_queries=late, invalid_frac=inval)
+        clip = synth.make_clip(2000 + seed0 + k, V=V, T=T, H=H, W=W, N=N, late_queries=late, invalid_frac=inval, frame_period=4 if big else None)
         a = E.args_of(clip, E.DEV)
         with E._with_precision(m, prec):
             r1 = m(*a, iters=iters)
